@@ -1,0 +1,83 @@
+"""ctypes binding of libcurlhip.so (include/curl_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing the import of any
+op fails loudly.  The CPU arithmetic of this path lives in the reference (and in
+oracle/, which is test infrastructure); nothing here routes through either.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CURL_HIP_LIB", os.path.join(_HERE, "lib", "libcurlhip.so"))
+
+# include/curl_hip.h
+MASK_NONE, MASK_U8, MASK_F32 = 0, 1, 2
+F_EXACT_ORDER = 0x1
+F_PWL = 0x2
+F_TUNE_UNROLL_SHIFT = 8
+F_TUNE_NT_LOAD = 0x1000
+F_TUNE_NT_STORE = 0x2000
+F_TUNE_XCD_REMAP = 0x4000
+F_TUNE_NO_NT = 0x8000
+MAX_KNOTS = 256
+
+_c_f = ctypes.c_void_p  # device pointers travel as integers
+_i = ctypes.c_int
+_u = ctypes.c_uint
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "curl_version": (_i, []),
+    "curl_last_error": (ctypes.c_char_p, []),
+    "curl_workspace_bytes": (_sz, [_i, _i]),
+    "curl_apply_curve_f32": (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _u, _c_f]),
+    "curl_adjust_rgb_f32": (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
+    "curl_adjust_lab_f32": (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
+    "curl_adjust_hsv_f32": (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
+    "curl_rgb2lab_f32": (_i, [_c_f, _c_f, _i, _i, _i, _u, _c_f]),
+    "curl_lab2rgb_f32": (_i, [_c_f, _c_f, _i, _i, _i, _u, _c_f]),
+    "curl_rgb2hsv_f32": (_i, [_c_f, _c_f, _i, _i, _i, _u, _c_f]),
+    "curl_hsv2rgb_f32": (_i, [_c_f, _c_f, _i, _i, _i, _u, _c_f]),
+    "curl_lab_stage_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
+    "curl_layer_fwd_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz,
+                                _i, _i, _i, _i, _i, _i, _u, _c_f]),
+    "curl_u8hwc_to_f32chw": (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f]),
+    "curl_f32chw_to_u8hwc": (_i, [_c_f, _c_f, _i, _i, _i, _c_f]),
+}
+
+_lib = None
+
+
+class CurlHipError(RuntimeError):
+    """A HIP runtime error reported by libcurlhip.so (positive return code)."""
+
+
+def load():
+    """Load libcurlhip.so once.  Raises ImportError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"curl_amd: HIP library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Translate a C-ABI return code into the Python exception the reference's callers would see:
+    argument errors -> ValueError (torch raises on bad shapes), HIP errors -> CurlHipError."""
+    if rc == 0:
+        return
+    msg = load().curl_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise CurlHipError(f"{what}: {msg} (hipError {rc})")

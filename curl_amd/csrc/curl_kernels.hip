@@ -1,0 +1,777 @@
+// curl_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the CURL colour-curve path.
+//
+// Everything here is a streaming, per-pixel, HBM-bound pass over NCHW float32 planes:
+//   * one workgroup = 256 threads = 4 wavefronts of 64; each lane owns U float4 groups per plane,
+//     so every wave-instruction moves 1 KiB of one plane, perfectly coalesced;
+//   * blockIdx -> (image, chunk); everything that depends on the image (the collapsed curve
+//     coefficients) is wave-uniform and is fetched with scalar loads into SGPRs;
+//   * curves evaluated in the reference's exact summation order, and the paper-style PWL lookup,
+//     stage the slopes/knots of the image in LDS (broadcast reads / per-lane gathers);
+//   * no MFMA: there is no contraction on this path (roofline = HBM).
+//
+// Interface: include/curl_hip.h.  Arithmetic: curl_math.h (cites the reference line by line).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/curl_hip.h"
+#include "curl_math.h"
+
+using namespace curlm;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s", what);
+  return code;
+}
+static int hip_fail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout (floats, per image)
+//   [0..19]  (a,b) of curve c at [2c],[2c+1]   (segment order: see prep kernel)
+//   [20..22] regulariser of segment 0,1,2 ; [23] total
+//   [32..)   exp'd knots of every curve, segment after segment
+// ------------------------------------------------------------------------------------------------
+#define WS_COEF 0
+#define WS_REG 20
+#define WS_KNOTS 32
+#define MAX_CURVES 10
+
+static inline unsigned ws_stride(int n_knots) { return WS_KNOTS + ((unsigned)(n_knots + 3) & ~3u); }
+
+struct PrepArgs {
+  const float* raw[3];  // per segment: [B, ncurves*K] raw (pre-exp) parameters, NULL if absent
+  int ncurves[3];
+  int K[3];
+  float* ws;
+  float* reg_out;  // nullable, [B], assigned
+  unsigned stride;
+};
+
+// One workgroup per image.  exp in float64 (rounded once to float32: the best estimate of torch.exp's
+// float32 result), slopes in float32 as the reference forms them (curves.py:19), every sum in float64.
+__global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
+  __shared__ float sC[MAX_CURVES * CURL_MAX_KNOTS];
+  __shared__ float sReg[MAX_CURVES];
+  const unsigned b = blockIdx.x;
+  float* ws = a.ws + (size_t)b * a.stride;
+  int seg_off[4];
+  seg_off[0] = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) seg_off[s + 1] = seg_off[s] + (a.raw[s] ? a.ncurves[s] * a.K[s] : 0);
+  const int n_total = seg_off[3];
+  for (int i = threadIdx.x; i < n_total; i += 256) {
+    int s = (i >= seg_off[2]) ? 2 : (i >= seg_off[1]) ? 1 : 0;
+    int local = i - seg_off[s];
+    int per_img = a.ncurves[s] * a.K[s];
+    float r = a.raw[s][(size_t)b * per_img + local];
+    float c = (float)exp((double)r);  // curves.py:54,106,153
+    sC[i] = c;
+    ws[WS_KNOTS + i] = c;
+  }
+  __syncthreads();
+  // one thread per curve
+  int curve0[4];
+  curve0[0] = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) curve0[s + 1] = curve0[s] + (a.raw[s] ? a.ncurves[s] : 0);
+  const int n_curves = curve0[3];
+  const int c = threadIdx.x;
+  if (c < n_curves) {
+    int s = (c >= curve0[2]) ? 2 : (c >= curve0[1]) ? 1 : 0;
+    int K = a.K[s];
+    const float* C = sC + seg_off[s] + (c - curve0[s]) * K;
+    float ca, cb, creg;
+    collapse_curve(C, K, ca, cb, creg);
+    ws[WS_COEF + 2 * c] = ca;
+    ws[WS_COEF + 2 * c + 1] = cb;
+    sReg[c] = creg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+    float seg_reg[3] = {0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < 3; ++s) {
+      float r = 0.0f;
+      for (int k = curve0[s]; k < curve0[s + 1]; ++k) r += sReg[k];  // reg += per curve (curves.py:24)
+      seg_reg[s] = r;
+      ws[WS_REG + s] = r;
+    }
+    tot = (seg_reg[0] + seg_reg[1]) + seg_reg[2];  // model.py:172-174 (rgb + lab) + hsv
+    ws[WS_REG + 3] = tot;
+    if (a.reg_out) a.reg_out[b] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming skeleton
+// ------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned char v4b __attribute__((ext_vector_type(4)));
+
+struct StreamArgs {
+  const float* in;
+  float* out;
+  const void* mask;   // [B,1,H,W] u8 or f32, or NULL
+  const float* coef;  // workspace base (per-image stride below) or NULL
+  unsigned coef_stride;
+  unsigned n;                 // elements per plane in units of VEC floats
+  unsigned blocks_per_image;  // chunks per image
+  unsigned n_blocks;          // total
+  int mask_kind;
+  int nt_load, nt_store, xcd_remap;
+};
+
+template <int VEC>
+struct Pack;
+template <>
+struct Pack<4> {
+  typedef v4f T;
+  typedef v4b M;
+};
+template <>
+struct Pack<1> {
+  typedef float T;
+  typedef unsigned char M;
+};
+
+template <typename T>
+__device__ __forceinline__ T ld(const T* p, int nt) {
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
+template <typename T>
+__device__ __forceinline__ void st(T* p, T v, int nt) {
+  if (nt)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+__device__ __forceinline__ float lane(const v4f& v, int e) { return v[e]; }
+__device__ __forceinline__ float lane(const float& v, int) { return v; }
+__device__ __forceinline__ void set_lane(v4f& v, int e, float x) { v[e] = x; }
+__device__ __forceinline__ void set_lane(float& v, int, float x) { v = x; }
+__device__ __forceinline__ float mlane(const v4b& v, int e) { return v[e] ? 1.0f : 0.0f; }
+__device__ __forceinline__ float mlane(const unsigned char& v, int) { return v ? 1.0f : 0.0f; }
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  With the remap each XCD walks
+// one contiguous eighth of the batch, so its L2/fabric sees sequential DRAM pages.  Bijective for any
+// n_blocks: ids in the ragged tail keep their place.
+__device__ __forceinline__ unsigned remap_block(unsigned bid, unsigned n_blocks, int on) {
+  if (!on) return bid;
+  unsigned per = n_blocks >> 3;
+  unsigned body = per << 3;
+  if (bid >= body) return bid;
+  return (bid & 7u) * per + (bid >> 3);
+}
+
+// Op contract:  struct Op { struct K {...}; static K load(const float* ws_image);  // uniform
+//                           static Px apply(Px in, float m, const K&); static constexpr bool kMask; }
+template <class Op, int VEC, int U>
+__global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
+  typedef typename Pack<VEC>::T T;
+  typedef typename Pack<VEC>::M M;
+  const unsigned bid = remap_block(blockIdx.x, a.n_blocks, a.xcd_remap);
+  const unsigned img = bid / a.blocks_per_image;
+  const unsigned chunk = bid - img * a.blocks_per_image;
+  const typename Op::K k = Op::load(a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr);
+  const size_t plane = (size_t)a.n;
+  const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
+  T* q0 = reinterpret_cast<T*>(a.out) + (size_t)img * 3 * plane;
+  const unsigned base = chunk * (256u * U) + threadIdx.x;
+
+  T x0[U], x1[U], x2[U];
+  T mf[U];
+  M mb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * 256u;
+    if (i < a.n) {
+      x0[u] = ld(p0 + i, a.nt_load);
+      x1[u] = ld(p0 + plane + i, a.nt_load);
+      x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
+      if (Op::kMask) {
+        if (a.mask_kind == CURL_MASK_U8)
+          mb[u] = ld(reinterpret_cast<const M*>(a.mask) + (size_t)img * plane + i, a.nt_load);
+        else if (a.mask_kind == CURL_MASK_F32)
+          mf[u] = ld(reinterpret_cast<const T*>(a.mask) + (size_t)img * plane + i, a.nt_load);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * 256u;
+    if (i < a.n) {
+      T y0, y1, y2;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float m = 1.0f;
+        if (Op::kMask) {
+          if (a.mask_kind == CURL_MASK_U8)
+            m = mlane(mb[u], e);
+          else if (a.mask_kind == CURL_MASK_F32)
+            m = lane(mf[u], e);
+        }
+        Px o = Op::apply(Px{lane(x0[u], e), lane(x1[u], e), lane(x2[u], e)}, m, k);
+        set_lane(y0, e, o.c0);
+        set_lane(y1, e, o.c1);
+        set_lane(y2, e, o.c2);
+      }
+      st(q0 + i, y0, a.nt_store);
+      st(q0 + plane + i, y1, a.nt_store);
+      st(q0 + 2 * plane + i, y2, a.nt_store);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ops
+// ------------------------------------------------------------------------------------------------
+struct NoK {};
+#define CONVERTER_OP(NAME, FN)                                               \
+  struct NAME {                                                              \
+    typedef NoK K;                                                           \
+    static constexpr bool kMask = false;                                     \
+    static __device__ __forceinline__ K load(const float*) { return K{}; }   \
+    static __device__ __forceinline__ Px apply(Px p, float, const K&) { return FN(p); } \
+  };
+CONVERTER_OP(OpRgb2Lab, rgb2lab)
+CONVERTER_OP(OpLab2Rgb, lab2rgb)
+CONVERTER_OP(OpRgb2Hsv, rgb2hsv)
+CONVERTER_OP(OpHsv2Rgb, hsv2rgb)
+
+__device__ __forceinline__ Affine load_affine(const float* ws, int c) {
+  return Affine{ws[WS_COEF + 2 * c], ws[WS_COEF + 2 * c + 1]};
+}
+
+struct OpAdjust3 {  // adjust_rgb / adjust_lab, affine form
+  struct K {
+    Affine k[3];
+  };
+  static constexpr bool kMask = false;
+  static __device__ __forceinline__ K load(const float* ws) {
+    K k;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
+    return k;
+  }
+  static __device__ __forceinline__ Px apply(Px p, float, const K& k) { return adjust3(p, k.k[0], k.k[1], k.k[2]); }
+};
+struct OpAdjustHsv {
+  struct K {
+    Affine k[4];
+  };
+  static constexpr bool kMask = false;
+  static __device__ __forceinline__ K load(const float* ws) {
+    K k;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) k.k[c] = load_affine(ws, c);
+    return k;
+  }
+  static __device__ __forceinline__ Px apply(Px p, float, const K& k) {
+    return adjust_hsv4(p, k.k[0], k.k[1], k.k[2], k.k[3]);
+  }
+};
+struct OpLabStage {
+  struct K {
+    Affine k[3];
+  };
+  static constexpr bool kMask = true;
+  static __device__ __forceinline__ K load(const float* ws) {
+    K k;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
+    return k;
+  }
+  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return lab_stage(p, m, k.k); }
+};
+struct OpLayer {
+  typedef LayerCoef K;
+  static constexpr bool kMask = true;
+  static __device__ __forceinline__ K load(const float* ws) {
+    K k;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) k.lab[c] = load_affine(ws, c);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) k.rgb[c] = load_affine(ws, 3 + c);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) k.hsv[c] = load_affine(ws, 6 + c);
+    return k;
+  }
+  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return curl_layer(p, m, k); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// curve chain with the knots in LDS: reference summation order, or paper-style PWL lookup
+// ------------------------------------------------------------------------------------------------
+#define CHAIN_MAX 4
+struct ChainArgs {
+  const float* in;
+  float* out;
+  const float* knots;  // exp'd knots; step s of image b at knots + b*knot_stride + knot_off[s]
+  unsigned knot_stride;
+  int n_steps;
+  int K;  // knots per curve (same for every step)
+  int knot_off[CHAIN_MAX];
+  int cin[CHAIN_MAX], cout[CHAIN_MAX];
+  unsigned n, blocks_per_image, n_blocks;
+  int mode;  // 0 affine (collapsed in the prologue), 1 exact order, 2 PWL
+  int nt_load, nt_store;
+};
+
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
+  typedef typename Pack<VEC>::T T;
+  __shared__ float sC[CHAIN_MAX][CURL_MAX_KNOTS];
+  __shared__ float sS[CHAIN_MAX][CURL_MAX_KNOTS];
+  __shared__ float sAB[CHAIN_MAX][2];
+  const unsigned bid = blockIdx.x;
+  const unsigned img = bid / a.blocks_per_image;
+  const unsigned chunk = bid - img * a.blocks_per_image;
+  const int K = a.K;
+  // stage this image's knots and slopes in LDS
+  for (int i = threadIdx.x; i < a.n_steps * K; i += 256) {
+    int s = i / K, j = i - s * K;
+    const float* C = a.knots + (size_t)img * a.knot_stride + a.knot_off[s];
+    float c = C[j];
+    sC[s][j] = c;
+    if (j + 1 < K) sS[s][j] = C[j + 1] - c;  // curves.py:19
+  }
+  __syncthreads();
+  if (a.mode == 0 && (int)threadIdx.x < a.n_steps) {
+    int s = threadIdx.x;
+    float creg;
+    collapse_curve(sC[s], K, sAB[s][0], sAB[s][1], creg);
+  }
+  if (a.mode == 0) __syncthreads();
+
+  const size_t plane = (size_t)a.n;
+  const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
+  T* q0 = reinterpret_cast<T*>(a.out) + (size_t)img * 3 * plane;
+  const unsigned base = chunk * (256u * U) + threadIdx.x;
+  T x0[U], x1[U], x2[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * 256u;
+    if (i < a.n) {
+      x0[u] = ld(p0 + i, a.nt_load);
+      x1[u] = ld(p0 + plane + i, a.nt_load);
+      x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
+    }
+  }
+  const float S = (float)(K - 1);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * 256u;
+    if (i < a.n) {
+      T y0, y1, y2;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float c0 = lane(x0[u], e), c1 = lane(x1[u], e), c2 = lane(x2[u], e);
+        for (int s = 0; s < a.n_steps; ++s) {
+          const int ci = a.cin[s], co = a.cout[s];
+          float xin = (ci == 0) ? c0 : (ci == 1) ? c1 : c2;
+          float scale;
+          if (a.mode == 1)
+            scale = scale_exact(xin, sS[s], sC[s][0], K - 2, S);
+          else if (a.mode == 2)
+            scale = scale_pwl(xin, sC[s], sS[s], K);
+          else
+            scale = fmaf(sAB[s][1], xin, sAB[s][0]);
+          // curves.py:35-36: multiply the output channel, clamp the whole image
+          float m0 = (co == 0) ? scale : 1.0f, m1 = (co == 1) ? scale : 1.0f, m2 = (co == 2) ? scale : 1.0f;
+          c0 = clamp01(c0 * m0);
+          c1 = clamp01(c1 * m1);
+          c2 = clamp01(c2 * m2);
+        }
+        set_lane(y0, e, c0);
+        set_lane(y1, e, c1);
+        set_lane(y2, e, c2);
+      }
+      st(q0 + i, y0, a.nt_store);
+      st(q0 + plane + i, y1, a.nt_store);
+      st(q0 + 2 * plane + i, y2, a.nt_store);
+    }
+  }
+}
+
+// reg[b] += sum of squared slope differences of C[b,:]  (curves.py:19,24), C already exp'd.
+__global__ void curve_reg_kernel(const float* C, float* reg, int B, int K) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float ca, cb, creg;
+  collapse_curve(C + (size_t)b * K, K, ca, cb, creg);
+  reg[b] += creg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout edges: u8 HWC <-> f32 CHW
+// ------------------------------------------------------------------------------------------------
+// One thread per pixel; HWC bytes of a wave are one contiguous 192/256-byte run, CHW floats three
+// coalesced 256-byte runs.
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* in, float* out, size_t HW, int Cin,
+                                                              size_t total) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // pixel index over B*HW
+  if (i >= total) return;
+  size_t b = i / HW, p = i - b * HW;
+  const uint8_t* s = in + i * Cin;
+  float* d = out + b * 3 * HW + p;
+  const float k = 255.0f;
+  d[0] = (float)s[0] / k;  // to_tensor: byte -> float, div(255)
+  d[HW] = (float)s[1] / k;
+  d[2 * HW] = (float)s[2] / k;
+}
+__global__ __launch_bounds__(256) void f32chw_to_u8hwc_kernel(const float* in, uint8_t* out, size_t HW,
+                                                              size_t total) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  size_t b = i / HW, p = i - b * HW;
+  const float* s = in + b * 3 * HW + p;
+  uint8_t* d = out + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = s[c * HW] * 255.0f;             // evaluate.py:64
+    v = fminf(fmaxf(v, 0.0f), 255.0f);        // astype('uint8') of out-of-range is undefined: saturate
+    d[c] = (uint8_t)(int)v;                   // truncation toward zero
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int check_img(const void* in, const void* out, int B, int H, int W) {
+  if (!in || !out) return fail(CURL_E_NULL, "image pointer is NULL");
+  if (B <= 0 || H <= 0 || W <= 0) return fail(CURL_E_SHAPE, "B, H, W must be positive");
+  if ((uint64_t)H * (uint64_t)W > 0x7fffffffull) return fail(CURL_E_SHAPE, "H*W exceeds 2^31-1");
+  return 0;
+}
+static int check_flags(unsigned flags, unsigned allowed) {
+  const unsigned tune = CURL_F_TUNE_UNROLL_MASK | CURL_F_TUNE_NT_LOAD | CURL_F_TUNE_NT_STORE |
+                        CURL_F_TUNE_XCD_REMAP | CURL_F_TUNE_NO_NT;
+  if (flags & ~(allowed | tune)) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point");
+  if ((flags & CURL_F_EXACT_ORDER) && (flags & CURL_F_PWL))
+    return fail(CURL_E_FLAGS, "CURL_F_EXACT_ORDER and CURL_F_PWL are exclusive");
+  return 0;
+}
+
+struct Geometry {
+  int vec;       // 4 or 1
+  int unroll;    // 1, 2 or 4
+  unsigned n;    // plane length in vec units
+  unsigned blocks_per_image, n_blocks;
+  int nt_load, nt_store, xcd;
+};
+
+// Library defaults chosen from the sweep in DESIGN.md (profiles/): float4, 2 groups per lane.
+#define DEFAULT_UNROLL 2
+#define DEFAULT_NT_LOAD 0
+#define DEFAULT_NT_STORE 0
+
+static int make_geometry(Geometry& g, const void* p0, const void* p1, const void* pm, int mask_kind, int B, int H, int W,
+                         unsigned flags) {
+  size_t HW = (size_t)H * W;
+  bool aligned = (HW % 4 == 0) && (((uintptr_t)p0 | (uintptr_t)p1) % 16 == 0);
+  if (pm && mask_kind == CURL_MASK_F32 && ((uintptr_t)pm % 16)) aligned = false;
+  if (pm && mask_kind == CURL_MASK_U8 && ((uintptr_t)pm % 4)) aligned = false;
+  g.vec = aligned ? 4 : 1;
+  int u = (int)((flags & CURL_F_TUNE_UNROLL_MASK) >> CURL_F_TUNE_UNROLL_SHIFT);
+  if (u == 0) u = DEFAULT_UNROLL;
+  if (u != 1 && u != 2 && u != 4) return fail(CURL_E_FLAGS, "tuning unroll must be 1, 2 or 4");
+  g.unroll = u;
+  g.n = (unsigned)(HW / g.vec);
+  unsigned per_block = 256u * (unsigned)u;
+  g.blocks_per_image = (g.n + per_block - 1) / per_block;
+  uint64_t nb = (uint64_t)g.blocks_per_image * (uint64_t)B;
+  if (nb > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
+  g.n_blocks = (unsigned)nb;
+  bool no_nt = flags & CURL_F_TUNE_NO_NT;
+  g.nt_load = no_nt ? 0 : ((flags & CURL_F_TUNE_NT_LOAD) ? 1 : DEFAULT_NT_LOAD);
+  g.nt_store = no_nt ? 0 : ((flags & CURL_F_TUNE_NT_STORE) ? 1 : DEFAULT_NT_STORE);
+  g.xcd = (flags & CURL_F_TUNE_XCD_REMAP) ? 1 : 0;
+  return 0;
+}
+
+template <class Op, int VEC>
+static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s) {
+  dim3 grid(g.n_blocks), block(256);
+  switch (g.unroll) {
+    case 1:
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 1>), grid, block, 0, s, a);
+      break;
+    case 2:
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 2>), grid, block, 0, s, a);
+      break;
+    default:
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 4>), grid, block, 0, s, a);
+      break;
+  }
+  return hipGetLastError();
+}
+
+template <class Op>
+static int launch_stream(const float* in, float* out, const void* mask, int mask_kind, const float* coef,
+                         unsigned coef_stride, int B, int H, int W, unsigned flags, hipStream_t s, const char* name) {
+  Geometry g;
+  if (int rc = make_geometry(g, in, out, mask, mask_kind, B, H, W, flags)) return rc;
+  StreamArgs a;
+  a.in = in;
+  a.out = out;
+  a.mask = mask;
+  a.coef = coef;
+  a.coef_stride = coef_stride;
+  a.n = g.n;
+  a.blocks_per_image = g.blocks_per_image;
+  a.n_blocks = g.n_blocks;
+  a.mask_kind = mask_kind;
+  a.nt_load = g.nt_load;
+  a.nt_store = g.nt_store;
+  a.xcd_remap = g.xcd;
+  hipError_t e = (g.vec == 4) ? launch_u<Op, 4>(g, a, s) : launch_u<Op, 1>(g, a, s);
+  if (e != hipSuccess) return hip_fail(e, name);
+  return 0;
+}
+
+static int check_mask(const void* mask, int mask_kind) {
+  if (mask_kind != CURL_MASK_NONE && mask_kind != CURL_MASK_U8 && mask_kind != CURL_MASK_F32)
+    return fail(CURL_E_MASK, "mask_kind must be 0 (none), 1 (u8) or 2 (f32)");
+  if (mask_kind != CURL_MASK_NONE && !mask) return fail(CURL_E_MASK, "mask_kind set but mask pointer is NULL");
+  return 0;
+}
+static int check_K(int K) {
+  if (K < 2 || K > CURL_MAX_KNOTS) return fail(CURL_E_KNOTS, "knots per curve must be in [2, CURL_MAX_KNOTS]");
+  return 0;
+}
+static int check_ws(const void* ws, size_t bytes, int B, int n_knots) {
+  if (!ws) return fail(CURL_E_WORKSPACE, "workspace is NULL");
+  if ((uintptr_t)ws % 16) return fail(CURL_E_WORKSPACE, "workspace must be 16-byte aligned");
+  if (bytes < curl_workspace_bytes(B, n_knots)) return fail(CURL_E_WORKSPACE, "workspace too small");
+  return 0;
+}
+
+static int run_prep(const float* r0, int n0, int K0, const float* r1, int n1, int K1, const float* r2, int n2, int K2,
+                    float* ws, unsigned stride, float* reg, int B, hipStream_t s) {
+  PrepArgs p;
+  p.raw[0] = r0;
+  p.raw[1] = r1;
+  p.raw[2] = r2;
+  p.ncurves[0] = n0;
+  p.ncurves[1] = n1;
+  p.ncurves[2] = n2;
+  p.K[0] = K0;
+  p.K[1] = K1;
+  p.K[2] = K2;
+  p.ws = ws;
+  p.reg_out = reg;
+  p.stride = stride;
+  hipLaunchKernelGGL(knots_prep_kernel, dim3(B), dim3(256), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "knots_prep_kernel");
+  return 0;
+}
+
+template <int VEC>
+static hipError_t launch_chain_u(const Geometry& g, const ChainArgs& a, hipStream_t s) {
+  dim3 grid(g.n_blocks), block(256);
+  switch (g.unroll) {
+    case 1:
+      hipLaunchKernelGGL((chain_kernel<VEC, 1>), grid, block, 0, s, a);
+      break;
+    case 2:
+      hipLaunchKernelGGL((chain_kernel<VEC, 2>), grid, block, 0, s, a);
+      break;
+    default:
+      hipLaunchKernelGGL((chain_kernel<VEC, 4>), grid, block, 0, s, a);
+      break;
+  }
+  return hipGetLastError();
+}
+
+static int launch_chain(const float* in, float* out, const float* knots, unsigned knot_stride, int n_steps, int K,
+                        const int* knot_off, const int* cin, const int* cout, int mode, int B, int H, int W,
+                        unsigned flags, hipStream_t s) {
+  Geometry g;
+  if (int rc = make_geometry(g, in, out, nullptr, 0, B, H, W, flags)) return rc;
+  ChainArgs a;
+  a.in = in;
+  a.out = out;
+  a.knots = knots;
+  a.knot_stride = knot_stride;
+  a.n_steps = n_steps;
+  a.K = K;
+  for (int i = 0; i < CHAIN_MAX; ++i) {
+    a.knot_off[i] = i < n_steps ? knot_off[i] : 0;
+    a.cin[i] = i < n_steps ? cin[i] : 0;
+    a.cout[i] = i < n_steps ? cout[i] : 0;
+  }
+  a.n = g.n;
+  a.blocks_per_image = g.blocks_per_image;
+  a.n_blocks = g.n_blocks;
+  a.mode = mode;
+  a.nt_load = g.nt_load;
+  a.nt_store = g.nt_store;
+  hipError_t e = (g.vec == 4) ? launch_chain_u<4>(g, a, s) : launch_chain_u<1>(g, a, s);
+  if (e != hipSuccess) return hip_fail(e, "chain_kernel");
+  return 0;
+}
+
+static int chain_mode(unsigned flags) { return (flags & CURL_F_EXACT_ORDER) ? 1 : (flags & CURL_F_PWL) ? 2 : 0; }
+
+extern "C" {
+
+int curl_version(void) { return 100; }  // 0.1.0
+
+const char* curl_last_error(void) { return g_err; }
+
+size_t curl_workspace_bytes(int B, int n_knots) {
+  if (B <= 0 || n_knots < 0) return 0;
+  return (size_t)B * ws_stride(n_knots) * sizeof(float);
+}
+
+int curl_apply_curve_f32(const float* img, const float* C, float* out, float* reg, int B, int H, int W, int K,
+                         int channel_in, int channel_out, unsigned flags, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!C) return fail(CURL_E_NULL, "C is NULL");
+  if (int rc = check_K(K)) return rc;
+  if (channel_in < 0 || channel_in > 2 || channel_out < 0 || channel_out > 2)
+    return fail(CURL_E_SHAPE, "channel_in/channel_out must be 0, 1 or 2");
+  if (int rc = check_flags(flags, CURL_F_EXACT_ORDER | CURL_F_PWL)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (reg) {
+    hipLaunchKernelGGL(curve_reg_kernel, dim3((B + 63) / 64), dim3(64), 0, s, C, reg, B, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "curve_reg_kernel");
+  }
+  int off[1] = {0}, ci[1] = {channel_in}, co[1] = {channel_out};
+  return launch_chain(img, out, C, (unsigned)K, 1, K, off, ci, co, chain_mode(flags), B, H, W, flags, s);
+}
+
+static int adjust_common(const float* img, const float* raw, float* out, float* reg, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int K, unsigned flags, curl_stream_t stream,
+                         int n_curves) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!raw) return fail(CURL_E_NULL, "raw knot pointer is NULL");
+  if (int rc = check_K(K)) return rc;
+  if (int rc = check_flags(flags, CURL_F_EXACT_ORDER | CURL_F_PWL)) return rc;
+  if (int rc = check_ws(workspace, workspace_bytes, B, n_curves * K)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  unsigned stride = ws_stride(n_curves * K);
+  if (int rc = run_prep(raw, n_curves, K, nullptr, 0, 0, nullptr, 0, 0, ws, stride, reg, B, s)) return rc;
+  int mode = chain_mode(flags);
+  if (mode == 0) {
+    if (n_curves == 3)
+      return launch_stream<OpAdjust3>(img, out, nullptr, 0, ws, stride, B, H, W, flags, s, "adjust3");
+    return launch_stream<OpAdjustHsv>(img, out, nullptr, 0, ws, stride, B, H, W, flags, s, "adjust_hsv");
+  }
+  int off[4], ci[4], co[4];
+  for (int c = 0; c < n_curves; ++c) off[c] = WS_KNOTS + c * K;
+  if (n_curves == 3) {
+    for (int c = 0; c < 3; ++c) ci[c] = co[c] = c;  // curves.py:113-126,160-173
+  } else {
+    ci[0] = 0, co[0] = 0;  // curves.py:61-62
+    ci[1] = 0, co[1] = 1;  // curves.py:67-68
+    ci[2] = 1, co[2] = 1;  // curves.py:73-74
+    ci[3] = 2, co[3] = 2;  // curves.py:79-80
+  }
+  return launch_chain(img, out, ws, stride, n_curves, K, off, ci, co, mode, B, H, W, flags, s);
+}
+
+int curl_adjust_rgb_f32(const float* img, const float* raw, float* out, float* reg, void* workspace,
+                        size_t workspace_bytes, int B, int H, int W, int K, unsigned flags, curl_stream_t stream) {
+  return adjust_common(img, raw, out, reg, workspace, workspace_bytes, B, H, W, K, flags, stream, 3);
+}
+int curl_adjust_lab_f32(const float* img, const float* raw, float* out, float* reg, void* workspace,
+                        size_t workspace_bytes, int B, int H, int W, int K, unsigned flags, curl_stream_t stream) {
+  return adjust_common(img, raw, out, reg, workspace, workspace_bytes, B, H, W, K, flags, stream, 3);
+}
+int curl_adjust_hsv_f32(const float* img, const float* raw, float* out, float* reg, void* workspace,
+                        size_t workspace_bytes, int B, int H, int W, int K, unsigned flags, curl_stream_t stream) {
+  return adjust_common(img, raw, out, reg, workspace, workspace_bytes, B, H, W, K, flags, stream, 4);
+}
+
+#define CONVERTER_ENTRY(FN, OP)                                                                              \
+  int FN(const float* in, float* out, int B, int H, int W, unsigned flags, curl_stream_t stream) {           \
+    g_err[0] = 0;                                                                                            \
+    if (int rc = check_img(in, out, B, H, W)) return rc;                                                     \
+    if (int rc = check_flags(flags, 0)) return rc;                                                           \
+    return launch_stream<OP>(in, out, nullptr, 0, nullptr, 0, B, H, W, flags, (hipStream_t)stream, #FN);     \
+  }
+CONVERTER_ENTRY(curl_rgb2lab_f32, OpRgb2Lab)
+CONVERTER_ENTRY(curl_lab2rgb_f32, OpLab2Rgb)
+CONVERTER_ENTRY(curl_rgb2hsv_f32, OpRgb2Hsv)
+CONVERTER_ENTRY(curl_hsv2rgb_f32, OpHsv2Rgb)
+
+int curl_lab_stage_f32(const float* img, const void* mask, int mask_kind, const float* rawL, float* out, float* reg,
+                       void* workspace, size_t workspace_bytes, int B, int H, int W, int Kl, unsigned flags,
+                       curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!rawL) return fail(CURL_E_NULL, "rawL is NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  if (int rc = check_K(Kl)) return rc;
+  if (int rc = check_flags(flags, 0)) return rc;
+  if (int rc = check_ws(workspace, workspace_bytes, B, 3 * Kl)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  unsigned stride = ws_stride(3 * Kl);
+  if (int rc = run_prep(rawL, 3, Kl, nullptr, 0, 0, nullptr, 0, 0, ws, stride, reg, B, s)) return rc;
+  return launch_stream<OpLabStage>(img, out, mask_kind ? mask : nullptr, mask_kind, ws, stride, B, H, W, flags, s,
+                                   "lab_stage");
+}
+
+int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind, const float* rawL, const float* rawR,
+                       const float* rawH, float* out, float* reg, void* workspace, size_t workspace_bytes, int B, int H,
+                       int W, int Kl, int Kr, int Kh, unsigned flags, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!rawL || !rawR || !rawH) return fail(CURL_E_NULL, "rawL/rawR/rawH must all be non-NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  if (int rc = check_K(Kl)) return rc;
+  if (int rc = check_K(Kr)) return rc;
+  if (int rc = check_K(Kh)) return rc;
+  if (int rc = check_flags(flags, 0)) return rc;
+  int n_knots = 3 * Kl + 3 * Kr + 4 * Kh;
+  if (int rc = check_ws(workspace, workspace_bytes, B, n_knots)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  unsigned stride = ws_stride(n_knots);
+  if (int rc = run_prep(rawL, 3, Kl, rawR, 3, Kr, rawH, 4, Kh, ws, stride, reg, B, s)) return rc;
+  return launch_stream<OpLayer>(img, out, mask_kind ? mask : nullptr, mask_kind, ws, stride, B, H, W, flags, s,
+                                "curl_layer");
+}
+
+int curl_u8hwc_to_f32chw(const uint8_t* in, float* out, int B, int H, int W, int Cin, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(in, out, B, H, W)) return rc;
+  if (Cin != 3 && Cin != 4) return fail(CURL_E_SHAPE, "Cin must be 3 (RGB) or 4 (RGBA)");
+  size_t HW = (size_t)H * W, total = HW * (size_t)B;
+  if ((total + 255) / 256 > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
+  hipLaunchKernelGGL(u8hwc_to_f32chw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, HW, Cin, total);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "u8hwc_to_f32chw");
+  return 0;
+}
+
+int curl_f32chw_to_u8hwc(const float* in, uint8_t* out, int B, int H, int W, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(in, out, B, H, W)) return rc;
+  size_t HW = (size_t)H * W, total = HW * (size_t)B;
+  if ((total + 255) / 256 > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
+  hipLaunchKernelGGL(f32chw_to_u8hwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, HW, total);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "f32chw_to_u8hwc");
+  return 0;
+}
+
+}  // extern "C"

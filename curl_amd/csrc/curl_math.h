@@ -1,0 +1,335 @@
+// curl_math.h -- per-pixel arithmetic of the CURL colour-curve path for gfx950.
+//
+// One header, two compilations:
+//   * hipcc (device): the kernels in curl_kernels.hip include it; transcendentals are the
+//     CDNA4 hardware instructions v_log_f32 / v_exp_f32 / v_rcp_f32 (quarter-rate VALU),
+//     clamps are v_med3_f32.
+//   * g++ (host, -DCURL_HOST_TWIN): tests/ build a test-only twin of the same arithmetic with
+//     libm standing in for the three hardware instructions, so the algebra (thresholds, tie
+//     handling, constant folding, error budget) is checked against the oracle in the CPU
+//     container.  The product never loads the twin: curl_amd/ binds libcurlhip.so only.
+//
+// Each function cites the reference lines it restates (paths under the reference tree).
+// Constants are the float32 roundings of the Python doubles the reference writes, because
+// torch casts a Python scalar to the tensor dtype before the op.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CURL_HD __host__ __device__ __forceinline__
+#else
+#define CURL_HD inline
+#endif
+
+namespace curlm {
+
+// ---------------------------------------------------------------- hardware primitives
+CURL_HD float hw_log2(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_logf(x);  // v_log_f32, 1 ulp, no denormal support (inputs here are >= 1e-4)
+#else
+  return log2f(x);
+#endif
+}
+CURL_HD float hw_exp2(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(x);  // v_exp_f32, 1 ulp (results here are >= 2^-14)
+#else
+  return exp2f(x);
+#endif
+}
+// 1/x to (almost always) correct rounding: v_rcp_f32 (1 ulp) + one Newton step (2 FMAs).
+CURL_HD float rcp_refined(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(x);
+  float e = fmaf(-x, r, 1.0f);
+  return fmaf(e, r, r);
+#else
+  return 1.0f / x;
+#endif
+}
+CURL_HD float clampf(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(x, lo, hi);  // v_med3_f32
+#else
+  return fminf(fmaxf(x, lo), hi);
+#endif
+}
+CURL_HD float clamp01(float x) { return clampf(x, 0.0f, 1.0f); }
+
+// ---------------------------------------------------------------- constants
+// colors.py:37-38 / 118-119
+constexpr float kSrgbThr = (float)0.04045;
+constexpr float kInv1292 = (float)(1.0 / 12.92);
+constexpr float kInv1055 = (float)(1.0 / 1.055);
+constexpr float kLinThr = (float)0.0031308;
+// x ** 2.4 : torch raises to float32(2.4) = 2.4000000953...; 2.4f - 2.0f is exact in float32.
+constexpr float kGammaFrac = (float)2.4 - 2.0f;
+constexpr float kInvGamma = (float)(1.0 / 2.4);
+constexpr float kThird = (float)(1.0 / 3.0);
+// colors.py:43-47 / 108-111
+constexpr double kEpsD = 6.0 / 29.0;
+constexpr float kEps = (float)kEpsD;
+constexpr float kEps3 = (float)(kEpsD * kEpsD * kEpsD);
+constexpr float k3Eps2 = (float)(3.0 * kEpsD * kEpsD);
+constexpr float kInv3Eps2 = (float)(1.0 / (3.0 * kEpsD * kEpsD));
+constexpr float k4_29 = (float)(4.0 / 29.0);
+constexpr float kFloor = (float)0.0001;  // clamp(min=0.0001) in front of every pow
+// colors.py:24,41 : XYZ is multiplied by the float32 reciprocals of the D65 white point
+constexpr float kInvXn = 1.0f / 0.950456f;
+constexpr float kInvZn = 1.0f / 1.088754f;
+constexpr float kXn = 0.950456f;
+constexpr float kZn = 1.088754f;
+// colors.py:205,240
+constexpr float kHsvFloor = (float)1e-9;
+
+struct Px {
+  float c0, c1, c2;
+};
+
+// ---------------------------------------------------------------- powers
+// x^2.4 for x >= (1e-4+0.055)/1.055: x*x * 2^(0.4*log2 x).  Splitting off x^2 keeps the
+// exponent argument below 2 in magnitude, so the hardware log/exp errors (1 ulp each) cost
+// ~2e-7 relative instead of ~7e-7.
+CURL_HD float pow_gamma(float x) { return (x * x) * hw_exp2(kGammaFrac * hw_log2(x)); }
+CURL_HD float pow_inv_gamma(float x) { return hw_exp2(kInvGamma * hw_log2(x)); }
+CURL_HD float cbrt_pos(float x) { return hw_exp2(kThird * hw_log2(x)); }
+
+// ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
+CURL_HD float srgb_to_linear(float x) {
+  // colors.py:37-38: both branches are evaluated and blended with 0/1 masks in the reference;
+  // a select gives the same value (the dead branch is finite, so it only adds +0).
+  float lin = x * kInv1292;
+  float gam = pow_gamma((fmaxf(x, kFloor) + 0.055f) * kInv1055);
+  return (x <= kSrgbThr) ? lin : gam;
+}
+CURL_HD float lab_f(float t) {
+  // colors.py:45-47
+  float lin = fmaf(t, kInv3Eps2, k4_29);
+  float cub = cbrt_pos(fmaxf(t, kFloor));
+  return (t <= kEps3) ? lin : cub;
+}
+CURL_HD Px rgb2lab(Px p) {
+  float r = srgb_to_linear(p.c0), g = srgb_to_linear(p.c1), b = srgb_to_linear(p.c2);
+  // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white)
+  float X = fmaf(0.180423f, b, fmaf(0.357580f, g, 0.412453f * r)) * kInvXn;
+  float Y = fmaf(0.072169f, b, fmaf(0.715160f, g, 0.212671f * r));
+  float Z = fmaf(0.950227f, b, fmaf(0.119193f, g, 0.019334f * r)) * kInvZn;
+  float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
+  // colors.py:18-20,50: L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz);
+  // colors.py:57-59: L/100, (a/110 + 1)/2, (b/110 + 1)/2 -- constants folded.
+  Px o;
+  o.c0 = fmaf(fy, 1.16f, -0.16f);
+  o.c1 = fmaf(fx - fy, (float)(500.0 / 220.0), 0.5f);
+  o.c2 = fmaf(fy - fz, (float)(200.0 / 220.0), 0.5f);
+  return o;
+}
+
+// ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
+CURL_HD float lab_finv(float f) {
+  // colors.py:110-111 ; x**3.0 is x*x*x in torch
+  float lin = k3Eps2 * (f - k4_29);
+  float c = fmaxf(f, kFloor);
+  float cub = c * c * c;
+  return (f <= kEps) ? lin : cub;
+}
+CURL_HD float linear_to_srgb(float v) {
+  // colors.py:118-119
+  float lin = v * 12.92f;
+  float gam = fmaf(pow_inv_gamma(fmaxf(v, kFloor)), 1.055f, -0.055f);
+  return (v <= kLinThr) ? lin : gam;
+}
+CURL_HD Px lab2rgb(Px p) {
+  // colors.py:97-99
+  float L = p.c0 * 100.0f;
+  float a = fmaf(p.c1, 2.0f, -1.0f) * 110.0f;
+  float b = fmaf(p.c2, 2.0f, -1.0f) * 110.0f;
+  // colors.py:79-81,104-106 with the float32 constants 1/116, 1/500, -1/200
+  float fy = (L + 16.0f) * (float)(1 / 116.0);
+  float fx = fmaf(a, (float)(1 / 500.0), fy);
+  float fz = fmaf(b, (float)(-1 / 200.0), fy);
+  // colors.py:114
+  float X = lab_finv(fx) * kXn, Y = lab_finv(fy), Z = lab_finv(fz) * kZn;
+  // colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
+  float r = fmaf(-0.4985314f, Z, fmaf(-1.5371385f, Y, 3.2404542f * X));
+  float g = fmaf(0.0415560f, Z, fmaf(1.8760108f, Y, -0.9692660f * X));
+  float bb = fmaf(1.0572252f, Z, fmaf(-0.2040259f, Y, 0.0556434f * X));
+  Px o;
+  o.c0 = linear_to_srgb(r);
+  o.c1 = linear_to_srgb(g);
+  o.c2 = linear_to_srgb(bb);
+  return o;  // NOT clamped (colors.py:121-123)
+}
+
+// ---------------------------------------------------------------- RGB -> HSV   colors.py:195-242
+CURL_HD Px rgb2hsv(Px p) {
+  float r = clampf(p.c0, kHsvFloor, 1.0f), g = clampf(p.c1, kHsvFloor, 1.0f), b = clampf(p.c2, kHsvFloor, 1.0f);
+  float mx = fmaxf(r, fmaxf(g, b));
+  float mn = fminf(r, fminf(g, b));
+  float df = mx - mn;
+  float dfi = rcp_refined(df);  // unused (selected away) when df == 0
+  // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum
+  float t0 = (r == mx) ? (g - b) * dfi : 0.0f;
+  float t1 = (g == mx) ? fmaf(b - r, dfi, 2.0f) : 0.0f;
+  float t2 = (b == mx) ? fmaf(r - g, dfi, 4.0f) : 0.0f;
+  float h = (df == 0.0f) ? 0.0f : (t0 + t1) + t2;
+  h = h * 60.0f;                        // colors.py:225
+  h = (h < 0.0f) ? h + 360.0f : h;      // colors.py:228-229
+  h = h * (float)(1.0 / 360.0);         // colors.py:231
+  float s = df * rcp_refined(mx);       // colors.py:234-237 (mx >= 1e-9 > 0 after the clamp)
+  Px o;
+  o.c0 = clampf(h, kHsvFloor, 1.0f);    // colors.py:240
+  o.c1 = clampf(s, kHsvFloor, 1.0f);
+  o.c2 = clampf(mx, kHsvFloor, 1.0f);
+  return o;
+}
+
+// ---------------------------------------------------------------- HSV -> RGB   colors.py:131-177
+CURL_HD Px hsv2rgb(Px p) {
+  float h = clamp01(p.c0) * 360.0f, s = clamp01(p.c1), v = clamp01(p.c2);
+  float q = v * (1.0f - s);
+  const float k60 = (float)(1.0 / 60.0);
+  float up = (v - q) * k60;   // colors.py:153,163
+  float dn = (q - v) * k60;   // colors.py:144
+  // the reference's identically-zero terms (m1,m3,m5 = 0) add +0 and are dropped
+  float r = v + clampf(h - 60.0f, 0.0f, 60.0f) * dn + clampf(h - 240.0f, 0.0f, 60.0f) * (-dn);
+  float g = q + clampf(h, 0.0f, 60.0f) * up + clampf(h - 180.0f, 0.0f, 60.0f) * (-up);
+  float b = q + clampf(h - 120.0f, 0.0f, 60.0f) * up + clampf(h - 300.0f, 0.0f, 60.0f) * (-up);
+  Px o;
+  o.c0 = clamp01(r);
+  o.c1 = clamp01(g);
+  o.c2 = clamp01(b);
+  return o;
+}
+
+// ---------------------------------------------------------------- curves   curves.py:4-38
+// Collapsed form of curves.py:31-32: with no clamp on (S*x - j) the sum is exactly
+// a + b*x,  a = C0 - sum_j j*slope_j,  b = S*sum_j slope_j  (j = 0..K-3).  (a,b) come from the
+// knot-prep kernel (float64 sums of the float32 slopes, rounded once).
+struct Affine {
+  float a, b;
+};
+CURL_HD float curve_mul(float x_out, float x_in, Affine k) { return x_out * fmaf(k.b, x_in, k.a); }
+
+// adjust_rgb / adjust_lab (curves.py:90-133,136-180): curves (0->0),(1->1),(2->2); EVERY apply_curve
+// clamps all three channels (curves.py:36), so channel 0 meets its curve unclamped while channels
+// 1 and 2 are clamped first.
+CURL_HD Px adjust3(Px p, Affine k0, Affine k1, Affine k2) {
+  Px o;
+  o.c0 = clamp01(curve_mul(p.c0, p.c0, k0));
+  float c1 = clamp01(p.c1), c2 = clamp01(p.c2);
+  o.c1 = clamp01(curve_mul(c1, c1, k1));
+  o.c2 = clamp01(curve_mul(c2, c2, k2));
+  return o;
+}
+// adjust_hsv (curves.py:41-87): H->H, H->S (on the ADJUSTED hue), S->S, V->V.
+CURL_HD Px adjust_hsv4(Px p, Affine k0, Affine k1, Affine k2, Affine k3) {
+  float h = clamp01(curve_mul(p.c0, p.c0, k0));
+  float s = clamp01(p.c1), v = clamp01(p.c2);
+  s = clamp01(curve_mul(s, h, k1));
+  s = clamp01(curve_mul(s, s, k2));
+  v = clamp01(curve_mul(v, v, k3));
+  Px o{h, s, v};
+  return o;
+}
+
+// Per-curve host/prep arithmetic: slopes in float32 as the reference forms them (curves.py:19), every
+// sum in float64, one rounding at the end.  reg = sum of squared slope differences (curves.py:24).
+CURL_HD void collapse_curve(const float* C, int K, float& a, float& b, float& reg) {
+  double sum_s = 0.0, sum_js = 0.0, r = 0.0;
+  float prev = 0.0f;
+  for (int j = 0; j + 1 < K; ++j) {
+    float sl = C[j + 1] - C[j];
+    if (j + 2 < K) {  // slopes 0..K-3 reach the pixels (curves.py:31: slope[:, :-1])
+      sum_s += (double)sl;
+      sum_js += (double)j * (double)sl;
+    }
+    if (j > 0) {
+      float d = sl - prev;
+      r += (double)(d * d);
+    }
+    prev = sl;
+  }
+  a = (float)((double)C[0] - sum_js);
+  b = (float)((double)(K - 1) * sum_s);
+  reg = (float)r;
+}
+
+// curves.py:31-32 in torch's evaluation order: t_j = slope_j * (S*x - j) rounded term by term, summed
+// by ATen's cascade sum (SumKernel.cpp multi_row_sum: sequential into acc0, flushed into acc1 every 16
+// terms and into acc2 every 256; acc0 += acc1; acc0 += acc2 at the end), then C0 + sum.  No FMA.
+CURL_HD float scale_exact(float x, const float* sl, float c0, int n_terms, float S) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  float sx = S * x;
+  float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+  int j = 0;
+  for (; j + 16 <= n_terms;) {
+    for (int e = 0; e < 16; ++e, ++j) {
+      float t = sx - (float)j;
+      float p = sl[j] * t;
+      acc0 = acc0 + p;
+    }
+    acc1 = acc1 + acc0;
+    acc0 = 0.0f;
+    if ((j & 0xF0) == 0) {
+      acc2 = acc2 + acc1;
+      acc1 = 0.0f;
+    }
+  }
+  for (; j < n_terms; ++j) {
+    float t = sx - (float)j;
+    float p = sl[j] * t;
+    acc0 = acc0 + p;
+  }
+  acc0 = acc0 + acc1;
+  acc0 = acc0 + acc2;
+  return c0 + acc0;
+}
+
+// Paper eq. (1) (increments clamped to [0,1]) -- NOT the reference's arithmetic, an explicit option:
+// scale = C_i + slope_i * frac, i = floor(S x) in [0, K-2].  Knots are uniformly spaced, so the
+// interval is a direct index (no search); on the device C and sl live in LDS and the two reads are
+// per-lane gathers.
+CURL_HD float scale_pwl(float x, const float* C, const float* sl, int K) {
+  float sx = (float)(K - 1) * x;
+  float fi = clampf(floorf(sx), 0.0f, (float)(K - 2));
+  int i = (int)fi;
+  float frac = clamp01(sx - fi);
+  return fmaf(sl[i], frac, C[i]);
+}
+
+struct LayerCoef {
+  Affine lab[3], rgb[3], hsv[4];
+};
+
+// model.py:151-157 : rgb2lab -> adjust_lab -> *mask -> lab2rgb
+CURL_HD Px lab_stage(Px in, float m, const Affine* k) {
+  Px lab = adjust3(rgb2lab(in), k[0], k[1], k[2]);
+  lab.c0 *= m;
+  lab.c1 *= m;
+  lab.c2 *= m;
+  return lab2rgb(lab);
+}
+
+// model.py:137-176 minus the dead `feat` lines
+CURL_HD Px curl_layer(Px in, float m, const LayerCoef& k) {
+  Px rgb = lab_stage(in, m, k.lab);
+  rgb = adjust3(rgb, k.rgb[0], k.rgb[1], k.rgb[2]);  // model.py:159
+  rgb.c0 *= m;                                       // model.py:160
+  rgb.c1 *= m;
+  rgb.c2 *= m;
+  Px hsv = adjust_hsv4(rgb2hsv(rgb), k.hsv[0], k.hsv[1], k.hsv[2], k.hsv[3]);  // model.py:163-165
+  hsv.c0 *= m;                                       // model.py:166
+  hsv.c1 *= m;
+  hsv.c2 *= m;
+  Px res = hsv2rgb(hsv);                             // model.py:169
+  Px o;
+  o.c0 = clamp01(in.c0 + res.c0) * m;                // model.py:170
+  o.c1 = clamp01(in.c1 + res.c1) * m;
+  o.c2 = clamp01(in.c2 + res.c2) * m;
+  return o;
+}
+
+}  // namespace curlm

@@ -1,0 +1,227 @@
+"""Tensor-level entry points: torch tensors in, HIP kernels underneath (via the C ABI).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream.
+Every function enqueues on torch's CURRENT stream and returns without synchronising.
+"""
+import torch
+
+from . import _lib
+from ._lib import F_EXACT_ORDER, F_PWL, MASK_F32, MASK_NONE, MASK_U8
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_device(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"curl_amd: {name} is on {t.device}; this path runs on a HIP device only "
+            "(no CPU fallback -- move the tensor to cuda)")
+
+
+def _image(t, name="img"):
+    _need_device(t, name)
+    if t.dim() != 4 or t.shape[1] != 3:
+        raise ValueError(f"{name} must be [B,3,H,W], got {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.numel() == 0:
+        raise ValueError(f"{name} is empty: {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _knots(t, name, ncurves, B):
+    _need_device(t, name)
+    if t.dim() != 2 or t.shape[0] != B:
+        raise ValueError(f"{name} must be [B={B}, {ncurves}*K], got {tuple(t.shape)}")
+    if t.shape[1] % ncurves != 0:
+        # torch.chunk would hand the last curve fewer knots (curves.py:53,105,152); not supported
+        raise ValueError(f"{name}: {t.shape[1]} parameters do not split into {ncurves} equal curves")
+    K = t.shape[1] // ncurves
+    if K < 2 or K > _lib.MAX_KNOTS:
+        raise ValueError(f"{name}: {K} knots per curve; supported range is [2, {_lib.MAX_KNOTS}]")
+    return t.to(torch.float32).contiguous(), K
+
+
+def _mask(mask, img):
+    """-> (tensor or None, mask_kind).  Accepts None, bool/uint8 or floating [B|1,1,H,W]."""
+    if mask is None:
+        return None, MASK_NONE
+    _need_device(mask, "mask")
+    B, _, H, W = img.shape
+    if mask.dim() == 3:
+        mask = mask.unsqueeze(1)
+    if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != H or mask.shape[3] != W \
+            or mask.shape[0] not in (1, B):
+        raise ValueError(f"mask must be [B,1,H,W] matching img {tuple(img.shape)}, got {tuple(mask.shape)}")
+    if mask.shape[0] != B:
+        mask = mask.expand(B, 1, H, W)
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8), MASK_U8
+    if mask.dtype == torch.uint8:
+        return mask.contiguous(), MASK_U8
+    if mask.is_floating_point():
+        return mask.to(torch.float32).contiguous(), MASK_F32
+    raise TypeError(f"mask dtype {mask.dtype} not supported (bool, uint8 or floating)")
+
+
+def _workspace(B, n_knots, device):
+    nbytes = _lib.load().curl_workspace_bytes(B, n_knots)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------ curves.py
+def apply_curve(img, C, slope_sqr_diff, channel_in, channel_out, flags=F_EXACT_ORDER):
+    """curves.apply_curve (curves.py:4-38).  C are the knots after exp, [B,K].
+    slope_sqr_diff [B] is updated in place (curves.py:24) and returned; None skips it."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, H, W = img.shape
+    Cc, K = _knots(C, "C", 1, B)
+    reg = slope_sqr_diff
+    if reg is not None:
+        _need_device(reg, "slope_sqr_diff")
+        if reg.shape != (B,) or reg.dtype != torch.float32 or not reg.is_contiguous():
+            raise ValueError("slope_sqr_diff must be a contiguous float32 [B] tensor")
+    out = torch.empty_like(img)
+    rc = lib.curl_apply_curve_f32(img.data_ptr(), Cc.data_ptr(), out.data_ptr(), _ptr(reg), B, H, W, K,
+                                  int(channel_in), int(channel_out), flags, _stream(img))
+    _lib.check(rc, "curl_apply_curve_f32")
+    return out, reg
+
+
+def _adjust(fn_name, ncurves, img, raw, flags):
+    lib = _lib.load()
+    img = _image(img)
+    B, _, H, W = img.shape
+    rawc, K = _knots(raw, "knots", ncurves, B)
+    out = torch.empty_like(img)
+    reg = torch.empty(B, dtype=torch.float32, device=img.device)
+    ws, nbytes = _workspace(B, ncurves * K, img.device)
+    rc = getattr(lib, fn_name)(img.data_ptr(), rawc.data_ptr(), out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes,
+                               B, H, W, K, flags, _stream(img))
+    _lib.check(rc, fn_name)
+    return out, reg
+
+
+def adjust_rgb(img, R, flags=0):
+    """curves.adjust_rgb (curves.py:90-133), regulariser seeded with zeros."""
+    return _adjust("curl_adjust_rgb_f32", 3, img, R, flags)
+
+
+def adjust_lab(img, L, flags=0):
+    """curves.adjust_lab (curves.py:136-180)."""
+    return _adjust("curl_adjust_lab_f32", 3, img, L, flags)
+
+
+def adjust_hsv(img, S, flags=0):
+    """curves.adjust_hsv (curves.py:41-87)."""
+    return _adjust("curl_adjust_hsv_f32", 4, img, S, flags)
+
+
+# ------------------------------------------------------------------ colors.py
+def _convert(fn_name, img, flags=0):
+    lib = _lib.load()
+    img = _image(img)
+    B, _, H, W = img.shape
+    out = torch.empty_like(img)
+    rc = getattr(lib, fn_name)(img.data_ptr(), out.data_ptr(), B, H, W, flags, _stream(img))
+    _lib.check(rc, fn_name)
+    return out
+
+
+def rgb2lab(img, flags=0):
+    """colors.RGB2LAB.forward (colors.py:27-62)."""
+    return _convert("curl_rgb2lab_f32", img, flags)
+
+
+def lab2rgb(img, flags=0):
+    """colors.LAB2RGB.forward (colors.py:88-123)."""
+    return _convert("curl_lab2rgb_f32", img, flags)
+
+
+def rgb2hsv(img, flags=0):
+    """colors.RGB2HSV.forward (colors.py:195-242)."""
+    return _convert("curl_rgb2hsv_f32", img, flags)
+
+
+def hsv2rgb(img, flags=0):
+    """colors.HSV2RGB.forward (colors.py:131-177)."""
+    return _convert("curl_hsv2rgb_f32", img, flags)
+
+
+# ------------------------------------------------------------------ model.py: fused stages
+def lab_stage(img, mask, L, flags=0, out=None):
+    """RGB -> Lab -> 3 curves -> *mask -> RGB in one pass (model.py:151-157). -> (rgb, reg_lab)."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, H, W = img.shape
+    Lc, Kl = _knots(L, "L", 3, B)
+    m, kind = _mask(mask, img)
+    out = torch.empty_like(img) if out is None else out
+    reg = torch.empty(B, dtype=torch.float32, device=img.device)
+    ws, nbytes = _workspace(B, 3 * Kl, img.device)
+    rc = lib.curl_lab_stage_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), out.data_ptr(), reg.data_ptr(),
+                                ws.data_ptr(), nbytes, B, H, W, Kl, flags, _stream(img))
+    _lib.check(rc, "curl_lab_stage_f32")
+    return out, reg
+
+
+def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
+    """CURLLayer.forward (model.py:137-176) in one pass over the pixels. -> (img, reg[B]).
+    L [B,3*Kl], R [B,3*Kr], H [B,4*Kh] are the already-sliced raw knots."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, Hh, W = img.shape
+    Lc, Kl = _knots(L, "L", 3, B)
+    Rc, Kr = _knots(R, "R", 3, B)
+    Hc, Kh = _knots(H, "H", 4, B)
+    m, kind = _mask(mask, img)
+    if out is None:
+        out = torch.empty_like(img)
+    reg = torch.empty(B, dtype=torch.float32, device=img.device)
+    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
+    rc = lib.curl_layer_fwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
+                                out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, Kl, Kr, Kh,
+                                flags, _stream(img))
+    _lib.check(rc, "curl_layer_fwd_f32")
+    return out, reg
+
+
+# ------------------------------------------------------------------ layout edges
+def u8hwc_to_f32chw(x):
+    """uint8 [B,H,W,3|4] (or [H,W,C]) -> float32 [B,3,H,W] = value/255 (infer.py:35-40, transpose.py:19-31)."""
+    lib = _lib.load()
+    _need_device(x, "x")
+    if x.dtype != torch.uint8:
+        raise TypeError(f"expected uint8, got {x.dtype}")
+    squeeze = x.dim() == 3
+    if squeeze:
+        x = x.unsqueeze(0)
+    if x.dim() != 4 or x.shape[3] not in (3, 4):
+        raise ValueError(f"expected [B,H,W,3|4], got {tuple(x.shape)}")
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(lib.curl_u8hwc_to_f32chw(x.data_ptr(), out.data_ptr(), B, H, W, C, _stream(x)), "curl_u8hwc_to_f32chw")
+    return out[0] if squeeze else out
+
+
+def f32chw_to_u8hwc(x):
+    """float32 [B,3,H,W] (or [3,H,W]) -> uint8 [B,H,W,3], (x*255) TRUNCATED (evaluate.py:64-66)."""
+    lib = _lib.load()
+    squeeze = isinstance(x, torch.Tensor) and x.dim() == 3
+    if squeeze:
+        x = x.unsqueeze(0)
+    x = _image(x, "x")
+    B, _, H, W = x.shape
+    out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.curl_f32chw_to_u8hwc(x.data_ptr(), out.data_ptr(), B, H, W, _stream(x)), "curl_f32chw_to_u8hwc")
+    return out[0] if squeeze else out

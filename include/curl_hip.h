@@ -1,0 +1,134 @@
+/* curl_hip.h -- C ABI of libcurlhip.so: the MI355X (gfx950) implementation of the
+ * CURL per-pixel colour-curve hot path.
+ *
+ * The reference (danielbulhosa/CURL) has no FFI: its boundary for this path is a set
+ * of Python call signatures over eager torch ops.  Each entry point below REPLACES one
+ * of those call sites; the citation after "replaces:" is the reference interface
+ * (file:line under the reference tree).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add at each site.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator
+ *     in practice); the library never allocates, frees or retains device memory;
+ *   - images are float32, NCHW planar, contiguous: [B,3,H,W]; masks are [B,1,H,W];
+ *   - out may alias img (every pixel is read before it is written);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; 0 = default stream)
+ *     and the call returns without synchronising;
+ *   - re-entrant, no global mutable state; the error string is thread-local;
+ *   - return value: 0 = ok; <0 = argument error (CURL_E_*); >0 = a hipError_t.
+ *     No exception crosses the boundary and nothing calls exit().
+ *
+ * Semantics where the reference is broken as written: the
+ * adjust_* wrappers seed the regulariser with zeros(B); the layer skips the dead
+ * `feat` lines of model.py:152,158,164.
+ */
+#ifndef CURL_HIP_H
+#define CURL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* curl_stream_t; /* hipStream_t */
+
+enum {
+  CURL_OK = 0,
+  CURL_E_NULL = -1,      /* a required pointer is NULL */
+  CURL_E_SHAPE = -2,     /* B/H/W/K/channel out of range */
+  CURL_E_KNOTS = -3,     /* knot count unsupported (K < 2 or K > CURL_MAX_KNOTS) */
+  CURL_E_WORKSPACE = -4, /* workspace missing, misaligned or too small */
+  CURL_E_MASK = -5,      /* mask_kind invalid or mask pointer inconsistent with it */
+  CURL_E_FLAGS = -6      /* unknown flag bit */
+};
+
+#define CURL_MAX_KNOTS 256
+
+/* mask_kind */
+#define CURL_MASK_NONE 0 /* mask pointer ignored (treated as all ones) */
+#define CURL_MASK_U8 1   /* uint8/bool, non-zero = 1.0 (data.py:190 hands bool masks) */
+#define CURL_MASK_F32 2  /* float32, multiplied as is (infer.py:41) */
+
+/* flags */
+#define CURL_F_EXACT_ORDER 0x1u /* evaluate each curve as the in-order fp32 sum of curves.py:31-32
+                                   (no FMA contraction, torch's cascade order) instead of the collapsed
+                                   affine form a + b*x.  apply_curve / adjust_* only. */
+#define CURL_F_PWL 0x2u         /* paper-style piecewise-linear curve (clamp (S*x-j) to [0,1]) -- NOT the
+                                   reference's arithmetic; explicit non-parity option.  adjust_* and layer. */
+/* tuning bits (0 = library default; used by the bench sweep, never change results) */
+#define CURL_F_TUNE_UNROLL_SHIFT 8 /* bits 8..10: float4 groups per thread, 0 = default */
+#define CURL_F_TUNE_UNROLL_MASK 0x700u
+#define CURL_F_TUNE_NT_LOAD 0x1000u  /* non-temporal loads */
+#define CURL_F_TUNE_NT_STORE 0x2000u /* non-temporal stores */
+#define CURL_F_TUNE_XCD_REMAP 0x4000u /* contiguous chunk of the image batch per XCD */
+#define CURL_F_TUNE_NO_NT 0x8000u     /* force plain loads/stores where the default is non-temporal */
+
+int curl_version(void);
+/* Thread-local description of the last non-zero return on this thread ("" if none). */
+const char* curl_last_error(void);
+
+/* Bytes of device scratch the knot-driven entry points need (holds, per image, the 10 collapsed
+ * (a,b) pairs, per-space regularisers and the exp'd knots).  n_knots = total raw knots per image
+ * handed to that call (e.g. 160 for the layer, 48 for adjust_rgb). */
+size_t curl_workspace_bytes(int B, int n_knots);
+
+/* replaces: curves.apply_curve(img, C, slope_sqr_diff, channel_in, channel_out)  curves.py:4-38
+ * C [B,K] are the knots AFTER exp.  reg [B] may be NULL; otherwise reg[b] += sum of squared slope
+ * differences (in place, like curves.py:24).  The whole image is clamped to [0,1] (curves.py:36).
+ * Default = CURL_F_EXACT_ORDER semantics are available; flags=0 uses the affine collapse. */
+int curl_apply_curve_f32(const float* img, const float* C, float* out, float* reg,
+                         int B, int H, int W, int K, int channel_in, int channel_out,
+                         unsigned flags, curl_stream_t stream);
+
+/* replaces: curves.adjust_rgb(img, R) / adjust_lab(img, L) / adjust_hsv(img, S)
+ *           curves.py:90-133 / 136-180 / 41-87
+ * raw [B, 3*K] (rgb, lab) or [B, 4*K] (hsv): raw parameters, exp() is applied inside (curves.py:54,106,153).
+ * reg [B] (nullable) is ASSIGNED the regulariser (seeded with zero). */
+int curl_adjust_rgb_f32(const float* img, const float* raw, float* out, float* reg,
+                        void* workspace, size_t workspace_bytes,
+                        int B, int H, int W, int K, unsigned flags, curl_stream_t stream);
+int curl_adjust_lab_f32(const float* img, const float* raw, float* out, float* reg,
+                        void* workspace, size_t workspace_bytes,
+                        int B, int H, int W, int K, unsigned flags, curl_stream_t stream);
+int curl_adjust_hsv_f32(const float* img, const float* raw, float* out, float* reg,
+                        void* workspace, size_t workspace_bytes,
+                        int B, int H, int W, int K, unsigned flags, curl_stream_t stream);
+
+/* replaces: colors.RGB2LAB.forward colors.py:27-62 ; LAB2RGB.forward colors.py:88-123 ;
+ *           RGB2HSV.forward colors.py:195-242 ; HSV2RGB.forward colors.py:131-177 */
+int curl_rgb2lab_f32(const float* in, float* out, int B, int H, int W, unsigned flags, curl_stream_t stream);
+int curl_lab2rgb_f32(const float* in, float* out, int B, int H, int W, unsigned flags, curl_stream_t stream);
+int curl_rgb2hsv_f32(const float* in, float* out, int B, int H, int W, unsigned flags, curl_stream_t stream);
+int curl_hsv2rgb_f32(const float* in, float* out, int B, int H, int W, unsigned flags, curl_stream_t stream);
+
+/* replaces: the first stage of CURLLayer.forward closed back to RGB, model.py:151-157
+ *           (rgb2lab -> adjust_lab -> *mask -> lab2rgb) as ONE pass over the pixels.
+ * rawL [B, 3*Kl]. reg [B] (nullable) is assigned reg_lab. */
+int curl_lab_stage_f32(const float* img, const void* mask, int mask_kind, const float* rawL,
+                       float* out, float* reg, void* workspace, size_t workspace_bytes,
+                       int B, int H, int W, int Kl, unsigned flags, curl_stream_t stream);
+
+/* replaces: CURLLayer.forward(img, mask, L, R, H)  model.py:137-176, as ONE pass over the pixels.
+ * rawL [B,3*Kl], rawR [B,3*Kr], rawH [B,4*Kh] (the slices L[:, :48], R[:, :48], H[:, :64] of
+ * model.py:153,159,165, made contiguous by the caller).  reg [B] (nullable) is assigned
+ * reg_rgb + reg_lab + reg_hsv (model.py:172-174). */
+int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind,
+                       const float* rawL, const float* rawR, const float* rawH,
+                       float* out, float* reg, void* workspace, size_t workspace_bytes,
+                       int B, int H, int W, int Kl, int Kr, int Kh,
+                       unsigned flags, curl_stream_t stream);
+
+/* replaces: PIL + TF.to_tensor + transpose.swapimdims_HW3_3HW at the file edge
+ *           infer.py:35-40, data.py:133-158, transpose.py:19-31
+ * in: uint8 [B,H,W,Cin] with Cin = 3 or 4 (alpha dropped); out: float32 [B,3,H,W] = value/255. */
+int curl_u8hwc_to_f32chw(const uint8_t* in, float* out, int B, int H, int W, int Cin, curl_stream_t stream);
+/* replaces: (x*255).astype('uint8') + transpose.swapimdims_3HW_HW3   evaluate.py:64-66, transpose.py:4-16
+ * TRUNCATING conversion (values are expected in [0,1]; outside, they saturate to 0/255). */
+int curl_f32chw_to_u8hwc(const float* in, uint8_t* out, int B, int H, int W, curl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURL_HIP_H */

@@ -1,0 +1,331 @@
+"""CPU oracle for the CURL colour-curve hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a torch-eager CPU restatement of the arithmetic of the reference
+(danielbulhosa/CURL) for the path SURVEY.md section 8 scopes: curve application
+(curves.py), the four colour-space converters (colors.py), the layout swaps
+(transpose.py), the CURLLayer stage order (model.py:137-176) and the masked
+PSNR (metric.py:35-68).  It exists to CHECK the HIP kernels.  Only tests/,
+__graft_entry__.smoke() and the cpu_baseline leg of bench.py may import it;
+nothing under curl_amd/ does, and the product fails loudly without its HIP
+library instead of falling back to this code.
+
+Parity pin: tests/test_oracle_vs_reference.py compares every function here
+bit-for-bit with the reference's own modules imported from /root/reference
+(possible only in the build container), and tests/golden/*.npz holds outputs
+of the reference itself (generator: tests/golden/make_golden.py) that this
+file and the HIP path are both checked against wherever the reference cannot
+travel.
+
+Semantics where the reference is broken as written:
+  * adjust_rgb/adjust_lab/adjust_hsv seed the regulariser with zeros(B)
+    (curves.py:56,111,155 seed None, which raises TypeError);
+  * curl_layer skips the three dead `feat` lines (model.py:152,158,164).
+
+Every function works in the dtype of its input (float32 = the reference's
+arithmetic; float64 gives a high-precision yardstick for judging rounding
+noise at the reference's own discontinuities).
+"""
+import math
+
+import numpy as np
+import torch
+
+# ---------------------------------------------------------------------------
+# constants (colors.py:8-25, 69-86)
+# ---------------------------------------------------------------------------
+_RGB_FROM_ROWS_TO_XYZ = [  # rows = R,G,B ; columns = X,Y,Z   (colors.py:10-12)
+    [0.412453, 0.212671, 0.019334],
+    [0.357580, 0.715160, 0.119193],
+    [0.180423, 0.072169, 0.950227],
+]
+_F_ROWS_TO_LAB = [  # rows = fx,fy,fz ; columns = L,a,b   (colors.py:18-20)
+    [0.0, 500.0, 0.0],
+    [116.0, -500.0, 200.0],
+    [0.0, 0.0, -200.0],
+]
+_XYZ_ROWS_TO_RGB = [  # rows = X,Y,Z ; columns = R,G,B   (colors.py:71-73)
+    [3.2404542, -0.9692660, 0.0556434],
+    [-1.5371385, 1.8760108, -0.2040259],
+    [-0.4985314, 0.0415560, 1.0572252],
+]
+_LAB_ROWS_TO_F = [  # rows = L+16,a,b ; columns = fx,fy,fz   (colors.py:79-81)
+    [1 / 116.0, 1 / 116.0, 1 / 116.0],
+    [1 / 500.0, 0, 0],
+    [0, 0, -1 / 200.0],
+]
+_D65 = [0.950456, 1.0, 1.088754]  # colors.py:24,85
+_LAB_OFFSET = [16.0, 0.0, 0.0]  # colors.py:25,86
+_EPS = 6 / 29  # colors.py:43,108
+
+
+def _param(rows, like, transpose=True):
+    """A constant as the reference holds it: built in float32 (colors.py:13,21,74,82),
+    then cast to the working dtype, laid out (1,1,3,3) after a transpose."""
+    t = torch.tensor(rows, dtype=torch.float)
+    if transpose:
+        t = t.transpose(1, 0)[None, None]
+    else:
+        t = t.reshape(1, 3, 1, 1)
+    return t.to(like.dtype)
+
+
+def _chan_mix(img, mat):
+    # colors.py:40,50,104,117 -- same einsum so the reduction order is the reference's.
+    return torch.einsum('bcyx,bykc->bkyx', img, mat)
+
+
+# ---------------------------------------------------------------------------
+# curves.py
+# ---------------------------------------------------------------------------
+def curve_regulariser(C):
+    """Sum of squared second differences of the knots, per image (curves.py:19,24)."""
+    seg = C[:, 1:] - C[:, :-1]
+    return ((seg[:, 1:] - seg[:, :-1]) ** 2).sum(1)
+
+
+def curve_scale(x, C):
+    """Per-pixel multiplier of curves.py:29-32.  x: [B,H,W], C: [B,K] (already exp'd).
+
+    scale = C0 + sum_{j=0}^{K-3} slope_j * (S*x - j),  S = K-1, no clamp of (S*x - j):
+    the function is affine in x and the last knot never touches a pixel.
+    """
+    n_seg = C.shape[1] - 1
+    seg = C[:, 1:] - C[:, :-1]
+    used = seg[:, :-1]
+    idx = torch.arange(0, seg.shape[1] - 1)
+    lifted = n_seg * x.unsqueeze(1) - idx.reshape(1, -1, 1, 1)
+    return C[:, 0].reshape(-1, 1, 1) + (used.reshape(used.shape[0], used.shape[1], 1, 1) * lifted).sum(1)
+
+
+def apply_curve(img, C, reg, channel_in, channel_out):
+    """curves.py:4-38.  Returns (new image, reg); reg is updated IN PLACE like the
+    reference does with `slope_sqr_diff +=` (curves.py:24)."""
+    reg += curve_regulariser(C)
+    scale = curve_scale(img[:, channel_in], C)
+    out = img.clone()
+    out[:, channel_out] = img[:, channel_out] * scale
+    out = torch.clamp(out, 0.0, 1.0)  # the WHOLE image, all channels (curves.py:36)
+    return out, reg
+
+
+def _adjust(img, raw, pairs):
+    """Shared body of curves.py:41-87, 90-133, 136-180 with the regulariser seeded at 0."""
+    img = img.contiguous()
+    knots = [torch.exp(p) for p in torch.chunk(raw, len(pairs), dim=1)]
+    reg = torch.zeros(img.shape[0], dtype=img.dtype)
+    for C, (cin, cout) in zip(knots, pairs):
+        img, reg = apply_curve(img, C, reg, cin, cout)
+    return img.contiguous(), reg
+
+
+def adjust_rgb(img, R):
+    """curves.py:90-133: R->R, G->G, B->B."""
+    return _adjust(img, R, [(0, 0), (1, 1), (2, 2)])
+
+
+def adjust_lab(img, L):
+    """curves.py:136-180: L->L, a->a, b->b (on Lab normalised to [0,1])."""
+    return _adjust(img, L, [(0, 0), (1, 1), (2, 2)])
+
+
+def adjust_hsv(img, S):
+    """curves.py:41-87: H->H, H->S (adjusted hue), S->S, V->V."""
+    return _adjust(img, S, [(0, 0), (0, 1), (1, 1), (2, 2)])
+
+
+# ---------------------------------------------------------------------------
+# colors.py
+# ---------------------------------------------------------------------------
+def rgb2lab(img):
+    """colors.py:27-62."""
+    img = img.contiguous()
+    lo = img.le(0.04045).to(img.dtype)
+    hi = img.gt(0.04045).to(img.dtype)
+    img = (img / 12.92) * lo + (((torch.clamp(img, min=0.0001) + 0.055) / 1.055) ** 2.4) * hi
+    img = _chan_mix(img, _param(_RGB_FROM_ROWS_TO_XYZ, img))
+    img = torch.mul(img, 1 / _param(_D65, img, transpose=False))
+    lo = img.le(_EPS ** 3).to(img.dtype)
+    hi = img.gt(_EPS ** 3).to(img.dtype)
+    img = ((img / (3.0 * _EPS ** 2) + 4.0 / 29.0) * lo) + (torch.clamp(img, min=0.0001) ** (1.0 / 3.0) * hi)
+    img = _chan_mix(img, _param(_F_ROWS_TO_LAB, img)) - _param(_LAB_OFFSET, img, transpose=False)
+    img[:, 0] = img[:, 0] / 100
+    img[:, 1] = (img[:, 1] / 110 + 1) / 2
+    img[:, 2] = (img[:, 2] / 110 + 1) / 2
+    return img.contiguous()
+
+
+def lab2rgb(img):
+    """colors.py:88-123.  Output is NOT clamped."""
+    img = img.contiguous()
+    c0 = (img[:, 0] * 100).unsqueeze(1)
+    c1 = (((img[:, 1] * 2) - 1) * 110).unsqueeze(1)
+    c2 = (((img[:, 2] * 2) - 1) * 110).unsqueeze(1)
+    img = torch.cat([c0, c1, c2], dim=1)
+    img = _chan_mix(img + _param(_LAB_OFFSET, img, transpose=False), _param(_LAB_ROWS_TO_F, img))
+    lo = img.le(_EPS).to(img.dtype)
+    hi = img.gt(_EPS).to(img.dtype)
+    img = ((3.0 * _EPS ** 2 * (img - 4.0 / 29.0)) * lo) + ((torch.clamp(img, min=0.0001) ** 3.0) * hi)
+    img = torch.mul(img, _param(_D65, img, transpose=False))
+    img = _chan_mix(img, _param(_XYZ_ROWS_TO_RGB, img))
+    lo = img.le(0.0031308).to(img.dtype)
+    hi = img.gt(0.0031308).to(img.dtype)
+    img = (img * 12.92 * lo) + ((torch.clamp(img, min=0.0001) ** (1 / 2.4) * 1.055) - 0.055) * hi
+    return img.contiguous()
+
+
+def _inv_or_zero(t):
+    """colors.py:186-193: 1/t where t != 0, else 0."""
+    out = 0.0 * t
+    nz = t != 0
+    out[nz] = 1 / (t[nz])
+    return out
+
+
+def rgb2hsv(img):
+    """colors.py:195-242.  Hue terms ADD on channel ties; lower clamp is 1e-9."""
+    img = torch.clamp(img, 10 ** (-9), 1.0).contiguous()
+    zero = torch.tensor(0.0, dtype=img.dtype)
+    mx = torch.max(img, 1)[0]
+    mn = torch.min(img, 1)[0]
+    df = torch.add(mx, -1.0 * mn)
+    r, g, b = img[:, 0], img[:, 1], img[:, 2]
+    df_inv = _inv_or_zero(df)
+    sextant = ((g - b) * df_inv) * r.eq(mx).to(img.dtype) \
+        + (2.0 + (b - r) * df_inv) * g.eq(mx).to(img.dtype) \
+        + (4.0 + (r - g) * df_inv) * b.eq(mx).to(img.dtype)
+    img[:, 0] = torch.where(df == 0.0, zero, sextant)  # overwrites r: g, b views stay valid
+    img[:, 0] = img[:, 0] * 60.0
+    img[:, 0] = img[:, 0].lt(0.0).to(img.dtype) * (img[:, 0] + 360) + img[:, 0].ge(0.0).to(img.dtype) * (img[:, 0])
+    img[:, 0] = img[:, 0] / 360
+    mx_inv = _inv_or_zero(mx)
+    img[:, 1] = torch.where(mx == 0.0, zero,
+                            mx.ne(0.0).to(img.dtype) * (df * mx_inv) + mx.eq(0.0).to(img.dtype) * (0.0))
+    img[:, 2] = mx
+    return torch.clamp(img, 10 ** (-9), 1.0)
+
+
+def hsv2rgb(img):
+    """colors.py:131-177."""
+    img = torch.clamp(img, 0.0, 1.0)
+    h360 = img[:, 0] * 360
+    s = img[:, 1]
+    v = img[:, 2]
+
+    def ramp(start, width):
+        return torch.clamp(h360 - start, 0.0, width)
+
+    # colors.py:143-150 (the identically-zero m1,m3,m5 terms add +0 and are kept for the
+    # evaluation order of the sum)
+    m2 = (v * (1 - s) - v) / 60
+    m4 = -1 * m2
+    r = v + ramp(0, 60.0) * 0 + ramp(60, 60.0) * m2 + ramp(120, 120.0) * 0 + ramp(240, 60.0) * m4 + ramp(300, 60.0) * 0
+    # colors.py:153-159
+    m1 = (v - v * (1 - s)) / 60
+    m3 = -1 * m1
+    g = v * (1 - s) + ramp(0, 60.0) * m1 + ramp(60, 120.0) * 0 + ramp(180, 60.0) * m3 + ramp(240, 120.0) * 0
+    # colors.py:162-168
+    m2 = (v - v * (1 - s)) / 60
+    m4 = -1 * m2
+    b = v * (1 - s) + ramp(0, 120.0) * 0 + ramp(120, 60.0) * m2 + ramp(180, 120.0) * 0 + ramp(300, 60.0) * m4
+    out = torch.stack((r, g, b), 1).contiguous()
+    return torch.clamp(out, 0.0, 1.0)
+
+
+# ---------------------------------------------------------------------------
+# model.py: CURLLayer stage order
+# ---------------------------------------------------------------------------
+def lab_stage(img, mask, L, num_lab_points=48):
+    """First stage of CURLLayer.forward, closed back to RGB (model.py:151-157):
+    RGB -> Lab -> 3 curves -> * mask -> RGB.  Returns (rgb, reg_lab)."""
+    lab = rgb2lab(img)
+    lab, reg = adjust_lab(lab, L[:, :num_lab_points])
+    lab = lab * mask
+    return lab2rgb(lab), reg
+
+
+def curl_layer(img, mask, L, R, H, num_lab_points=48, num_rgb_points=48, num_hsv_points=64):
+    """CURLLayer.forward (model.py:137-176) minus the dead `feat` lines."""
+    rgb, reg_lab = lab_stage(img, mask, L, num_lab_points)
+    rgb, reg_rgb = adjust_rgb(rgb, R[:, :num_rgb_points])
+    rgb = rgb * mask
+    hsv = rgb2hsv(rgb)
+    hsv, reg_hsv = adjust_hsv(hsv, H[:, :num_hsv_points])
+    hsv = hsv * mask
+    residual = hsv2rgb(hsv)
+    out = torch.clamp(img + residual, 0.0, 1.0) * mask
+    return out, (reg_rgb + reg_lab + reg_hsv)
+
+
+def split_knots(flat, num_lab_points=48, num_rgb_points=48):
+    """GCURLNet.forward's split of the encoder output (model.py:186-187,197-199)."""
+    b1 = num_lab_points
+    b2 = num_lab_points + num_rgb_points
+    return flat[:, :b1], flat[:, b1:b2], flat[:, b2:]
+
+
+# ---------------------------------------------------------------------------
+# metric.py: masked PSNR
+# ---------------------------------------------------------------------------
+def psnr(a, b, mask, max_intensity=1.0):
+    """metric.py:35-68: per-image masked PSNR, nan-mean over the batch."""
+    a = torch.clamp(a, 0.0, 1.0) * mask
+    b = torch.clamp(b, 0.0, 1.0) * mask
+    n = a.shape[1] * torch.squeeze(mask, dim=1).sum(dim=(1, 2))
+    mse = ((a - b) ** 2).sum(dim=(1, 2, 3)) / n
+    val = (10 * torch.log10(max_intensity ** 2 / mse)).nanmean()
+    return None if val.isnan() else val
+
+
+# ---------------------------------------------------------------------------
+# transpose.py / evaluate.py:64 / infer.py:37-47 : layout edges
+# ---------------------------------------------------------------------------
+def chw_to_hwc(arr):
+    """transpose.py:4-16 (3-D and 4-D numpy arrays; returns a view)."""
+    if arr.ndim == 3:
+        return np.transpose(arr, (1, 2, 0))
+    if arr.ndim == 4:
+        return np.transpose(arr, (0, 2, 3, 1))
+    return None
+
+
+def hwc_to_chw(arr):
+    """transpose.py:19-31."""
+    if arr.ndim == 3:
+        return np.transpose(arr, (2, 0, 1))
+    if arr.ndim == 4:
+        return np.transpose(arr, (0, 3, 1, 2))
+    return None
+
+
+def u8hwc_to_f32chw(arr_u8):
+    """What PIL + TF.to_tensor do at the file edge (infer.py:37, data.py:133-158):
+    uint8 HWC (3 or 4 channels, alpha dropped) -> float32 CHW, value/255."""
+    a = np.asarray(arr_u8)[..., :3]
+    t = torch.from_numpy(np.ascontiguousarray(hwc_to_chw(a)))
+    return t.to(torch.float32).div(255)
+
+
+def f32chw_to_u8hwc(t):
+    """evaluate.py:64-66: (x*255).astype('uint8') -- TRUNCATION, then CHW->HWC.
+    Values are expected in [0,1] (the layer clamps)."""
+    a = (t.numpy() * 255).astype('uint8')
+    return np.ascontiguousarray(chw_to_hwc(a))
+
+
+def white_background(img, mask):
+    """infer.py:46: out*mask + (1-mask)."""
+    return img * mask + (1 - mask)
+
+
+def affine_coefficients(C):
+    """Exact-arithmetic collapse of curve_scale: scale(x) = a + b*x with
+    a = C0 - sum_j j*slope_j, b = S*sum_j slope_j (j = 0..K-3), evaluated in float64
+    from the float32 slopes.  Used by tests to bound |affine - in-order fp32| noise;
+    it is the form the fused HIP kernels evaluate."""
+    C32 = C.to(torch.float32)
+    seg = (C32[:, 1:] - C32[:, :-1]).to(torch.float64)[:, :-1]
+    j = torch.arange(seg.shape[1], dtype=torch.float64)
+    S = float(C.shape[1] - 1)
+    a = C32[:, 0].to(torch.float64) - (seg * j).sum(1)
+    b = S * seg.sum(1)
+    return a, b

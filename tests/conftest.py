@@ -1,0 +1,114 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = os.environ.get("CURL_REFERENCE", "/root/reference")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+@pytest.fixture(scope="session")
+def reference_modules():
+    """The reference's own curves/colors/transpose/metric modules -- build container only."""
+    if not os.path.isfile(os.path.join(REFERENCE, "curves.py")):
+        pytest.skip("reference tree not present (it never travels to the GPU box)")
+    sys.path.insert(0, REFERENCE)
+    try:
+        import colors
+        import curves
+        import metric
+        import transpose
+    finally:
+        sys.path.remove(REFERENCE)
+    return {"curves": curves, "colors": colors, "transpose": transpose, "metric": metric}
+
+
+@pytest.fixture(scope="session")
+def twin():
+    """Test-only host build of curl_amd/csrc/curl_math.h (tests/twin/curl_twin.cpp)."""
+    src = os.path.join(ROOT, "tests", "twin", "curl_twin.cpp")
+    hdr = os.path.join(ROOT, "curl_amd", "csrc", "curl_math.h")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libcurl_twin.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                               "-DCURL_HOST_TWIN", "-Wno-unknown-pragmas", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    fp = ctypes.POINTER(ctypes.c_float)
+
+    def P(a):
+        return None if a is None else a.ctypes.data_as(fp)
+
+    def f32(a):
+        return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+    class Twin:
+        @staticmethod
+        def convert(op, x):
+            x = f32(x)
+            out = np.empty_like(x)
+            B, _, H, W = x.shape
+            lib.twin_convert({"rgb2lab": 0, "lab2rgb": 1, "rgb2hsv": 2, "hsv2rgb": 3}[op], P(x), P(out), B,
+                             ctypes.c_long(H * W))
+            return out
+
+        @staticmethod
+        def apply_curve(img, C, reg, cin, cout, mode):
+            img, C = f32(img), f32(C)
+            out = np.empty_like(img)
+            reg = None if reg is None else f32(reg).copy()
+            B, _, H, W = img.shape
+            lib.twin_apply_curve(P(img), P(C), P(out), P(reg), B, ctypes.c_long(H * W), C.shape[1], cin, cout, mode)
+            return out, reg
+
+        @staticmethod
+        def adjust(ncurves, img, raw, mode=0):
+            img, raw = f32(img), f32(raw)
+            out = np.empty_like(img)
+            B, _, H, W = img.shape
+            reg = np.empty(B, np.float32)
+            lib.twin_adjust(ncurves, P(img), P(raw), P(out), P(reg), B, ctypes.c_long(H * W), raw.shape[1] // ncurves,
+                            mode)
+            return out, reg
+
+        @staticmethod
+        def layer(stage, img, mask, L, R, H):
+            img, mask, L, R, H = f32(img), f32(mask), f32(L), f32(R), f32(H)
+            out = np.empty_like(img)
+            B, _, Hh, W = img.shape
+            reg = np.empty(B, np.float32)
+            lib.twin_layer(stage, P(img), P(mask), P(L), P(R), P(H), P(out), P(reg), B, ctypes.c_long(Hh * W),
+                           L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4)
+            return out, reg
+
+    return Twin
+
+
+def max_err(a, b):
+    """max|a-b| / max(1, max|b|) -- absolute error in image units."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))

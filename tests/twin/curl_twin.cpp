@@ -1,0 +1,130 @@
+// curl_twin.cpp -- TEST-ONLY host twin of the kernel arithmetic.
+//
+// Compiles curl_amd/csrc/curl_math.h (the exact header the gfx950 kernels include) with g++, libm
+// standing in for v_log_f32 / v_exp_f32 / v_rcp_f32, and loops it over host arrays.  tests/ use it in
+// the CPU container to check the kernels' algebra against the oracle and the golden vectors before
+// anything goes to the GPU box.  The product (curl_amd/) never loads this library.
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../curl_amd/csrc/curl_math.h"
+
+using namespace curlm;
+
+static void prep(const float* raw, int ncurves, int K, Affine* k, float* knots, float& reg) {
+  reg = 0.0f;
+  for (int c = 0; c < ncurves; ++c) {
+    float* C = knots + c * K;
+    for (int j = 0; j < K; ++j) C[j] = (float)std::exp((double)raw[c * K + j]);
+    float r;
+    collapse_curve(C, K, k[c].a, k[c].b, r);
+    reg += r;
+  }
+}
+
+extern "C" {
+
+// op: 0 rgb2lab, 1 lab2rgb, 2 rgb2hsv, 3 hsv2rgb
+int twin_convert(int op, const float* in, float* out, int B, long HW) {
+  for (int b = 0; b < B; ++b)
+    for (long i = 0; i < HW; ++i) {
+      const float* p = in + (size_t)b * 3 * HW + i;
+      Px x{p[0], p[HW], p[2 * HW]}, y;
+      switch (op) {
+        case 0: y = rgb2lab(x); break;
+        case 1: y = lab2rgb(x); break;
+        case 2: y = rgb2hsv(x); break;
+        default: y = hsv2rgb(x); break;
+      }
+      float* q = out + (size_t)b * 3 * HW + i;
+      q[0] = y.c0, q[HW] = y.c1, q[2 * HW] = y.c2;
+    }
+  return 0;
+}
+
+// mode: 0 affine, 1 exact order, 2 pwl.  C already exp'd, [B,K].  reg (nullable) +=.
+int twin_apply_curve(const float* img, const float* C, float* out, float* reg, int B, long HW, int K, int cin,
+                     int cout, int mode) {
+  std::vector<float> sl(K);
+  for (int b = 0; b < B; ++b) {
+    const float* c = C + (size_t)b * K;
+    for (int j = 0; j + 1 < K; ++j) sl[j] = c[j + 1] - c[j];
+    float a, bb, r;
+    collapse_curve(c, K, a, bb, r);
+    if (reg) reg[b] += r;
+    for (long i = 0; i < HW; ++i) {
+      const float* p = img + (size_t)b * 3 * HW + i;
+      float ch[3] = {p[0], p[HW], p[2 * HW]};
+      float x = ch[cin];
+      float s = mode == 1 ? scale_exact(x, sl.data(), c[0], K - 2, (float)(K - 1))
+                          : mode == 2 ? scale_pwl(x, c, sl.data(), K) : fmaf(bb, x, a);
+      ch[cout] *= s;
+      float* q = out + (size_t)b * 3 * HW + i;
+      q[0] = clamp01(ch[0]), q[HW] = clamp01(ch[1]), q[2 * HW] = clamp01(ch[2]);
+    }
+  }
+  return 0;
+}
+
+// ncurves 3 (rgb/lab) or 4 (hsv); raw [B, ncurves*K]
+int twin_adjust(int ncurves, const float* img, const float* raw, float* out, float* reg, int B, long HW, int K,
+                int mode) {
+  const int cin4[4] = {0, 0, 1, 2}, cout4[4] = {0, 1, 1, 2};
+  std::vector<float> knots(ncurves * K), sl(K);
+  for (int b = 0; b < B; ++b) {
+    Affine k[4];
+    float r;
+    prep(raw + (size_t)b * ncurves * K, ncurves, K, k, knots.data(), r);
+    if (reg) reg[b] = r;
+    for (long i = 0; i < HW; ++i) {
+      const float* p = img + (size_t)b * 3 * HW + i;
+      Px x{p[0], p[HW], p[2 * HW]}, y;
+      if (mode == 0) {
+        y = ncurves == 3 ? adjust3(x, k[0], k[1], k[2]) : adjust_hsv4(x, k[0], k[1], k[2], k[3]);
+      } else {
+        float ch[3] = {x.c0, x.c1, x.c2};
+        for (int s = 0; s < ncurves; ++s) {
+          const float* c = knots.data() + s * K;
+          for (int j = 0; j + 1 < K; ++j) sl[j] = c[j + 1] - c[j];
+          int ci = ncurves == 3 ? s : cin4[s], co = ncurves == 3 ? s : cout4[s];
+          float sc = mode == 1 ? scale_exact(ch[ci], sl.data(), c[0], K - 2, (float)(K - 1))
+                               : scale_pwl(ch[ci], c, sl.data(), K);
+          ch[co] *= sc;
+          for (int e = 0; e < 3; ++e) ch[e] = clamp01(ch[e]);
+        }
+        y = Px{ch[0], ch[1], ch[2]};
+      }
+      float* q = out + (size_t)b * 3 * HW + i;
+      q[0] = y.c0, q[HW] = y.c1, q[2 * HW] = y.c2;
+    }
+  }
+  return 0;
+}
+
+// stage 0: lab_stage (rawR/rawH ignored), 1: full layer.  mask: float [B,HW] or NULL.
+int twin_layer(int stage, const float* img, const float* mask, const float* rawL, const float* rawR,
+               const float* rawH, float* out, float* reg, int B, long HW, int Kl, int Kr, int Kh) {
+  std::vector<float> knots(4 * 256);
+  for (int b = 0; b < B; ++b) {
+    LayerCoef k;
+    float rl = 0, rr = 0, rh = 0;
+    prep(rawL + (size_t)b * 3 * Kl, 3, Kl, k.lab, knots.data(), rl);
+    if (stage == 1) {
+      prep(rawR + (size_t)b * 3 * Kr, 3, Kr, k.rgb, knots.data(), rr);
+      prep(rawH + (size_t)b * 4 * Kh, 4, Kh, k.hsv, knots.data(), rh);
+    }
+    if (reg) reg[b] = (rl + rr) + rh;
+    for (long i = 0; i < HW; ++i) {
+      const float* p = img + (size_t)b * 3 * HW + i;
+      float m = mask ? mask[(size_t)b * HW + i] : 1.0f;
+      Px x{p[0], p[HW], p[2 * HW]};
+      Px y = stage == 0 ? lab_stage(x, m, k.lab) : curl_layer(x, m, k);
+      float* q = out + (size_t)b * 3 * HW + i;
+      q[0] = y.c0, q[HW] = y.c1, q[2 * HW] = y.c2;
+    }
+  }
+  return 0;
+}
+}
