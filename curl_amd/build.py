@@ -1,0 +1,33 @@
+"""Build libcurlhip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m curl_amd.build            # or __graft_entry__.build()
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "curl_kernels.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "curl_math.h"), os.path.join(os.path.dirname(HERE), "include", "curl_hip.h")]
+OUT = os.path.join(HERE, "lib", "libcurlhip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-math-errno"]
+
+
+def build(force=False, verbose=False):
+    """Compile curl_amd/csrc/curl_kernels.hip -> curl_amd/lib/libcurlhip.so (in-tree, so it travels with the repo)."""
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-o", OUT, SRC]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building libcurlhip.so")
+    if verbose:
+        sys.stderr.write(res.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,58 @@
+"""Multi-GPU layout of the curve path: one process per GPU.
+
+Default: images shard across ranks; every pixel depends only on its own three values and its own
+image's 160 knots, so there is NO data-path collective.  Optional shared-encoder / split-pixels
+layout: the knots ([B,160] float32, 640 B per image) are the only thing that crosses xGMI -- one
+broadcast or all-gather over RCCL -- and each rank applies them to its row slab of every image.
+"""
+import torch
+import torch.distributed as dist
+
+
+def image_shard(n_images, rank, world):
+    """Contiguous, balanced [start, stop) of the batch for `rank` (first n%world ranks get one extra)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, extra = divmod(n_images, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def row_slab(height, rank, world):
+    """Rows [r0, r1) of every image owned by `rank` in the split-pixels layout."""
+    return image_shard(height, rank, world)
+
+
+def broadcast_knots(knots, src=0, group=None):
+    """Shared-encoder layout: rank `src` ran the encoder; everyone receives the raw knots [B,160].
+    `knots` must be allocated with the right shape on every rank (contents ignored off `src`)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(knots, src=src, group=group)
+    return knots
+
+
+def allgather_knots(local_knots, group=None):
+    """Each rank encoded its image shard ([b_local,160]); returns the knots of the whole batch in rank order.
+    Shards may differ by one row (image_shard); they are padded to the longest for the collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_knots
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([local_knots.shape[0]], device=local_knots.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    padded = local_knots.new_zeros((longest, local_knots.shape[1]))
+    padded[: local_knots.shape[0]] = local_knots
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
+
+
+def apply_row_slab(layer, img, mask, L, R, H, rank, world):
+    """Split-pixels layout: apply the layer to this rank's rows of every image. Returns (slab_out, reg, (r0, r1))."""
+    r0, r1 = row_slab(img.shape[2], rank, world)
+    sub = img[:, :, r0:r1, :].contiguous()
+    sub_mask = None if mask is None else mask[:, :, r0:r1, :].contiguous()
+    out, reg = layer(sub, sub_mask, L, R, H)
+    return out, reg, (r0, r1)

@@ -1,0 +1,94 @@
+"""The C-ABI library loads (no GPU needed) and exports exactly what include/curl_hip.h declares;
+argument errors are reported through return codes + curl_last_error, never by crashing."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "curl_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:int|size_t|const char\*)\s+(curl_\w+)\s*\(", src, flags=re.M)
+    assert len(names) >= 15
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from curl_amd import _lib
+    lib = _lib.load()
+    names = declared_functions()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in curl_hip.h but not exported"
+    assert sorted(names) == sorted(_lib.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_constants_match_header():
+    from curl_amd import _lib
+    src = open(HEADER).read()
+    defs = dict(re.findall(r"#define\s+(CURL_\w+)\s+(0x[0-9a-fA-F]+|\d+)u?", src))
+    assert int(defs["CURL_MASK_U8"]) == _lib.MASK_U8 and int(defs["CURL_MASK_F32"]) == _lib.MASK_F32
+    assert int(defs["CURL_F_EXACT_ORDER"], 16) == _lib.F_EXACT_ORDER and int(defs["CURL_F_PWL"], 16) == _lib.F_PWL
+    assert int(defs["CURL_MAX_KNOTS"]) == _lib.MAX_KNOTS
+    assert int(defs["CURL_F_TUNE_NT_LOAD"], 16) == _lib.F_TUNE_NT_LOAD
+    assert int(defs["CURL_F_TUNE_XCD_REMAP"], 16) == _lib.F_TUNE_XCD_REMAP
+
+
+def test_version_and_workspace_size():
+    from curl_amd import _lib
+    lib = _lib.load()
+    assert lib.curl_version() >= 100
+    assert lib.curl_workspace_bytes(32, 160) >= 32 * (20 + 160) * 4
+    assert lib.curl_workspace_bytes(0, 160) == 0 and lib.curl_workspace_bytes(1, 0) > 0
+
+
+def test_argument_errors_are_codes_not_crashes():
+    """Validation happens before any HIP call, so it can be exercised without a GPU."""
+    from curl_amd import _lib
+    lib = _lib.load()
+    assert lib.curl_rgb2lab_f32(None, None, 1, 4, 4, 0, None) == -1  # CURL_E_NULL
+    assert b"NULL" in lib.curl_last_error()
+    fake = ctypes.c_void_p(4096)
+    assert lib.curl_rgb2lab_f32(fake, fake, 0, 4, 4, 0, None) == -2  # CURL_E_SHAPE
+    assert lib.curl_rgb2lab_f32(fake, fake, 1, 4, 4, 0x2, None) == -6  # flag not valid for converters
+    assert lib.curl_apply_curve_f32(fake, fake, fake, None, 1, 4, 4, 1, 0, 0, 0, None) == -3  # K < 2
+    assert lib.curl_apply_curve_f32(fake, fake, fake, None, 1, 4, 4, 16, 3, 0, 0, None) == -2  # channel
+    assert lib.curl_apply_curve_f32(fake, fake, fake, None, 1, 4, 4, 16, 0, 0, 0x3, None) == -6  # exclusive flags
+    assert lib.curl_adjust_rgb_f32(fake, fake, fake, None, None, 0, 1, 4, 4, 16, 0, None) == -4  # workspace
+    assert lib.curl_adjust_rgb_f32(fake, fake, fake, None, fake, 8, 1, 4, 4, 16, 0, None) == -4  # too small
+    assert lib.curl_layer_fwd_f32(fake, None, 1, fake, fake, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 16, 16, 0,
+                                  None) == -5  # mask_kind set, mask NULL
+    assert lib.curl_layer_fwd_f32(fake, None, 7, fake, fake, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 16, 16, 0,
+                                  None) == -5
+    assert lib.curl_layer_fwd_f32(fake, None, 0, fake, fake, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 300, 16, 0,
+                                  None) == -3  # K > CURL_MAX_KNOTS
+    assert lib.curl_u8hwc_to_f32chw(fake, fake, 1, 4, 4, 2, None) == -2  # Cin
+    with pytest.raises(ValueError):
+        _lib.check(-2, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No fallback: a missing .so is an ImportError naming the build command."""
+    import importlib
+    from curl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    monkeypatch.undo()
+    importlib.reload(_lib)
+    _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "curl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "curl_oracle" not in txt and "libcurl_twin" not in txt, f

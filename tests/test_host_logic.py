@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference interface: validation, error behaviour, knot slicing, masks,
+state-dict compatibility -- everything that does not need a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from curl_amd import colors, curves, model, ops, shard, transpose
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    x = torch.rand(1, 3, 4, 4)
+    for fn in (ops.rgb2lab, ops.lab2rgb, ops.rgb2hsv, ops.hsv2rgb):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fn(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        curves.apply_curve(x, torch.ones(1, 16), torch.zeros(1), 0, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.CURLLayer()(x, None, torch.zeros(1, 48), torch.zeros(1, 48), torch.zeros(1, 64))
+
+
+def test_shape_and_dtype_validation(monkeypatch):
+    with pytest.raises(TypeError):
+        ops._image(np.zeros((1, 3, 2, 2)))
+    monkeypatch.setattr(ops, "_need_device", lambda t, name: None)
+    with pytest.raises(ValueError, match=r"\[B,3,H,W\]"):
+        ops._image(torch.zeros(1, 4, 2, 2))
+    with pytest.raises(ValueError):
+        ops._image(torch.zeros(3, 2, 2))
+    with pytest.raises(TypeError, match="float32"):
+        ops._image(torch.zeros(1, 3, 2, 2, dtype=torch.float64))
+    with pytest.raises(ValueError, match="empty"):
+        ops._image(torch.zeros(0, 3, 2, 2))
+    x = torch.zeros(2, 3, 4, 6)[:, :, :, ::2]  # non-contiguous view is accepted and made contiguous
+    assert ops._image(x).is_contiguous()
+
+
+def test_knot_validation_helpers(monkeypatch):
+    monkeypatch.setattr(ops, "_need_device", lambda t, name: None)
+    k, K = ops._knots(torch.zeros(2, 48), "R", 3, 2)
+    assert K == 16 and k.is_contiguous()
+    k, K = ops._knots(torch.zeros(2, 100)[:, :64], "H", 4, 2)  # the slice H[:, :64] of a wider head
+    assert K == 16 and k.is_contiguous()
+    with pytest.raises(ValueError, match="equal curves"):
+        ops._knots(torch.zeros(2, 50), "R", 3, 2)
+    with pytest.raises(ValueError, match="knots per curve"):
+        ops._knots(torch.zeros(2, 3), "R", 3, 2)
+    with pytest.raises(ValueError):
+        ops._knots(torch.zeros(3, 48), "R", 3, 2)
+
+
+def test_mask_handling(monkeypatch):
+    monkeypatch.setattr(ops, "_need_device", lambda t, name: None)
+    img = torch.zeros(2, 3, 4, 5)
+    assert ops._mask(None, img) == (None, 0)
+    m, kind = ops._mask(torch.ones(2, 1, 4, 5, dtype=torch.bool), img)
+    assert kind == 1 and m.dtype == torch.uint8
+    m, kind = ops._mask(torch.ones(1, 1, 4, 5), img)  # broadcast over the batch like torch would
+    assert kind == 2 and m.shape == (2, 1, 4, 5) and m.is_contiguous()
+    m, kind = ops._mask(torch.ones(2, 1, 4, 5, dtype=torch.float64), img)
+    assert kind == 2 and m.dtype == torch.float32
+    m, kind = ops._mask(torch.ones(2, 4, 5), img)
+    assert m.shape == (2, 1, 4, 5)
+    with pytest.raises(ValueError):
+        ops._mask(torch.ones(2, 3, 4, 5), img)
+    with pytest.raises(TypeError):
+        ops._mask(torch.ones(2, 1, 4, 5, dtype=torch.int32), img)
+
+
+def test_state_dict_keys_match_reference():
+    """Checkpoints of the reference carry the colour constants under these keys."""
+    layer = model.CURLLayer()
+    keys = set(layer.state_dict())
+    want = {"rgb2lab.rgb_to_xyz", "rgb2lab.fxfyfz_to_lab", "rgb2lab.xyz_to_rgb_mult", "rgb2lab.lab_to_fxfyfz_offset",
+            "lab2rgb.xyz_to_rgb", "lab2rgb.lab_to_fxfyfz", "lab2rgb.xyz_to_rgb_mult", "lab2rgb.lab_to_fxfyfz_offset",
+            "rgb2hsv.comparison_zero"}
+    assert want == keys
+    assert layer.state_dict()["rgb2lab.rgb_to_xyz"].shape == (1, 1, 3, 3)
+    assert not any(p.requires_grad for p in layer.parameters())
+
+
+def test_colour_constants_match_reference_modules(reference_modules):
+    ref = reference_modules["colors"]
+    for mine, theirs in ((colors.RGB2LAB(), ref.RGB2LAB()), (colors.LAB2RGB(), ref.LAB2RGB()),
+                         (colors.RGB2HSV(), ref.RGB2HSV())):
+        a, b = mine.state_dict(), theirs.state_dict()
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_gcurlnet_structure_and_split():
+    net = model.GCURLNet(backbone=model.CurveEncoder(num_outputs=160, width=0.25, num_features=64)).eval()
+    assert (net.curve_break_1, net.curve_break_2) == (48, 96)  # model.py:186-187
+    knots = net.predict_knots(torch.rand(2, 3, 64, 64))
+    assert knots.shape == (2, 160)
+    # an injected backbone with a mismatched Linear head gets the 160-wide head of model.py:190-192
+    bb = model.CurveEncoder(num_outputs=10, width=0.25, num_features=64)
+    net2 = model.GCURLNet(backbone=bb).eval()
+    assert net2.predict_knots(torch.rand(1, 3, 32, 32)).shape == (1, 160)
+    net3 = model.GCURLNet(backbone=model.CurveEncoder(160, 0.25, 64), encoder_size=32).eval()
+    assert net3.predict_knots(torch.rand(1, 3, 100, 75)).shape == (1, 160)
+
+
+def test_transpose_matches_golden(golden):
+    g = golden("layout")
+    assert np.array_equal(transpose.swapimdims_3HW_HW3(g["chw"]), g["chw_to_hwc"])
+    assert np.array_equal(transpose.swapimdims_3HW_HW3(g["bchw"]), g["bchw_to_bhwc"])
+    assert np.array_equal(transpose.swapimdims_HW3_3HW(g["chw_to_hwc"]), g["hwc_to_chw"])
+    assert np.array_equal(transpose.swapimdims_HW3_3HW(g["bchw_to_bhwc"]), g["bhwc_to_bchw"])
+    assert transpose.swapimdims_3HW_HW3(np.zeros((2, 2))) is None  # reference returns None for other ranks
+
+
+def test_image_shard_is_a_partition():
+    for n in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard.image_shard(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.image_shard(4, 2, 2)

@@ -1,0 +1,110 @@
+"""The kernel arithmetic (curl_amd/csrc/curl_math.h) compiled for the host by tests/twin, against the
+reference's golden vectors and the oracle.  libm replaces v_log_f32 / v_exp_f32 / v_rcp_f32, everything
+else (thresholds, tie handling, folded constants, curve collapse, cascade summation) is the code the
+GPU runs.  This is the CPU-side gate before a kernel change goes to the GPU box."""
+import numpy as np
+import pytest
+import torch
+
+import curl_oracle as O
+from conftest import max_err
+
+
+@pytest.mark.parametrize("op,inp,outp", [
+    ("rgb2lab", "rgb_in", "rgb2lab_out"), ("rgb2lab", "rgbwide_in", "rgb2lab_wide_out"),
+    ("lab2rgb", "lab_in", "lab2rgb_out"), ("rgb2hsv", "rgb_in", "rgb2hsv_out"),
+    ("rgb2hsv", "rgbwide_in", "rgb2hsv_wide_out"), ("hsv2rgb", "hsv_in", "hsv2rgb_out")])
+def test_converters(twin, golden, op, inp, outp):
+    g = golden("converters")
+    assert max_err(twin.convert(op, g[inp]), g[outp]) <= 1e-6
+
+
+def test_apply_curve_exact_order_is_bitexact(twin, golden):
+    g = golden("apply_curve")
+    for case, K, ci, co, which in g["meta"]:
+        x = g["in_wide" if which else "in_unit"]
+        out, reg = twin.apply_curve(x, g[f"c{case}_C"], g[f"c{case}_reg0"], int(ci), int(co), mode=1)
+        assert np.array_equal(out, g[f"c{case}_out"]), (case, K)
+        np.testing.assert_allclose(reg, g[f"c{case}_reg"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("K", [18, 19, 33, 40, 100, 256])
+def test_exact_order_follows_torch_cascade_sum(twin, K):
+    """K-2 > 16 terms: ATen's cascade sum flushes every 16 terms; the kernel mimics it (curl_math.h)."""
+    g = torch.Generator().manual_seed(K)
+    x = torch.rand(1, 3, 8, 16, generator=g) * 2 - 0.5
+    C = torch.exp(torch.randn(1, K, generator=g) * 0.3)
+    ref, _ = O.apply_curve(x, C, torch.zeros(1), 1, 2)
+    out, _ = twin.apply_curve(x.numpy(), C.numpy(), None, 1, 2, mode=1)
+    assert np.array_equal(out, ref.numpy())
+
+
+def test_affine_collapse_within_reference_noise(twin, golden):
+    g = golden("apply_curve")
+    for case, K, ci, co, which in g["meta"]:
+        x = g["in_wide" if which else "in_unit"]
+        out, _ = twin.apply_curve(x, g[f"c{case}_C"], None, int(ci), int(co), mode=0)
+        assert max_err(out, g[f"c{case}_out"]) <= 1e-5, case
+
+
+def test_pwl_mode_is_the_paper_curve(twin):
+    """Non-parity option: scale = piecewise-linear interpolation of the knots at x (paper eq. 1)."""
+    g = torch.Generator().manual_seed(3)
+    K = 16
+    x = torch.rand(1, 3, 4, 32, generator=g)
+    C = torch.exp(torch.randn(1, K, generator=g) * 0.3)
+    out, _ = twin.apply_curve(x.numpy(), C.numpy(), None, 0, 0, mode=2)
+    xs = x[0, 0].numpy().astype(np.float64)
+    scale = np.interp(xs * (K - 1), np.arange(K), C[0].numpy().astype(np.float64))
+    want = np.clip(xs * scale, 0, 1)
+    assert np.abs(out[0, 0] - want).max() < 1e-5
+
+
+@pytest.mark.parametrize("sig,tol", [("s01", 2e-6), ("s05", 1e-5)])
+def test_adjust(twin, golden, sig, tol):
+    c = golden("chain")
+    for name, n, key in (("rgb", 3, "_R"), ("lab", 3, "_L"), ("hsv", 4, "_H")):
+        for mode in (0, 1):
+            out, reg = twin.adjust(n, c["img"], c[sig + key], mode)
+            assert max_err(out, c[f"{sig}_adjust_{name}_out"]) <= tol, (name, mode)
+            np.testing.assert_allclose(reg, c[f"{sig}_adjust_{name}_reg"], rtol=2e-6)
+
+
+def test_layer_sigma01(twin, golden):
+    c = golden("chain")
+    L, R, H = c["s01_L"], c["s01_R"], c["s01_H"]
+    for inn in ("img", "img8"):
+        for mk in ("ones", "holes", "disk", "soft"):
+            key = f"s01_{inn}_{mk}"
+            if key + "_out" not in c:
+                continue
+            m = c["mask_" + mk].astype(np.float32)
+            out, reg = twin.layer(1, c[inn], m, L, R, H)
+            assert max_err(out, c[key + "_out"]) <= 1e-5, key
+            np.testing.assert_allclose(reg, c[key + "_reg"], rtol=2e-6)
+            ls, _ = twin.layer(0, c[inn], m, L, R, H)
+            assert max_err(ls, c[key + "_lab_stage"]) <= 1e-5, key
+
+
+def test_layer_error_is_reference_noise_sized(twin):
+    """On 0.5 Mpix the kernel arithmetic is no further from float64 truth than the reference's own float32
+    evaluation is (DESIGN.md 'Parity'): the chain is ill-conditioned at dark / near-grey pixels."""
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 2, 256, 512
+    img = torch.rand(B, 3, H, W, generator=g)
+    m = torch.ones(B, 1, H, W)
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (48, 48, 64))
+    for stage in (0, 1):
+        if stage == 0:
+            o32, _ = O.lab_stage(img, m, L)
+            o64, _ = O.lab_stage(img.double(), m.double(), L.double())
+        else:
+            o32, _ = O.curl_layer(img, m, L, R, Hk)
+            o64, _ = O.curl_layer(img.double(), m.double(), L.double(), R.double(), Hk.double())
+        tw, _ = twin.layer(stage, img.numpy(), m.numpy(), L.numpy(), R.numpy(), Hk.numpy())
+        ref_noise = np.abs(o32.numpy() - o64.numpy())
+        tw_noise = np.abs(tw - o64.numpy())
+        assert tw_noise.max() <= 1.5 * ref_noise.max() + 1e-6
+        assert tw_noise.mean() <= 1.5 * ref_noise.mean() + 1e-8
+        d = np.abs(tw - o32.numpy())
+        assert (d > 1e-5).mean() < 2e-4 and d.max() < 1e-4
