@@ -133,7 +133,9 @@ def cpu_baseline():
     R = torch.randn(B, 48, generator=g) * 0.1
     Hk = torch.randn(B, 64, generator=g) * 0.1
     mask = disk_mask(B, H_IMG, W_IMG, torch.device("cpu")).float()
-    threads = torch.get_num_threads()
+    # the 1-GPU box gives this job a 16-cpu share of a 256-cpu host: more threads than that only thrash
+    threads = max(1, min(torch.get_num_threads(), int(os.environ.get("CURL_CPU_THREADS", 16))))
+    torch.set_num_threads(threads)
     times = []
     with torch.no_grad():
         O.curl_layer(img[:1], mask[:1], L[:1], R[:1], Hk[:1])  # warm

@@ -58,6 +58,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime of the process, so that the
+    # device pointers and streams torch hands us belong to the runtime our kernels are launched on.  Loading
+    # this library first would bind /opt/rocm's copy instead (observed: hipErrorNoDevice at the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"curl_amd: HIP library not found at {LIB_PATH}. Build it with "

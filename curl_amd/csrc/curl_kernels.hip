@@ -126,7 +126,6 @@ struct StreamArgs {
   unsigned n;                 // elements per plane in units of VEC floats
   unsigned blocks_per_image;  // chunks per image
   unsigned n_blocks;          // total
-  int mask_kind;
   int nt_load, nt_store, xcd_remap;
 };
 
@@ -174,10 +173,65 @@ __device__ __forceinline__ unsigned remap_block(unsigned bid, unsigned n_blocks,
 
 // Op contract:  struct Op { struct K {...}; static K load(const float* ws_image);  // uniform
 //                           static Px apply(Px in, float m, const K&); static constexpr bool kMask; }
-template <class Op, int VEC, int U>
-__global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
+//
+// One block = one tile of 256*U vectors of ONE image: all loads of the tile are issued up front (7*U
+// independent 16-byte loads per lane), then the arithmetic, then the stores; latency is covered by the
+// other resident waves (a two-deep register prefetch loop was measured and lost to plain occupancy on every
+// kernel here: profiles/sweep_r01.md).  Loads clamp their index instead of branching (no divergent
+// prologue, no zero-fill); stores are guarded.
+template <int VEC, int U, int MK>
+struct Tile {
+  typename Pack<VEC>::T x0[U], x1[U], x2[U];
+  typename Pack<VEC>::T mf[MK == CURL_MASK_F32 ? U : 1];
+  typename Pack<VEC>::M mb[MK == CURL_MASK_U8 ? U : 1];
+};
+
+template <int VEC, int U, int MK>
+__device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs& a, const typename Pack<VEC>::T* p0,
+                                          size_t plane, size_t mask_off, unsigned base) {
   typedef typename Pack<VEC>::T T;
   typedef typename Pack<VEC>::M M;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = min(base + u * 256u, a.n - 1u);
+    t.x0[u] = ld(p0 + i, a.nt_load);
+    t.x1[u] = ld(p0 + plane + i, a.nt_load);
+    t.x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
+    if (MK == CURL_MASK_U8) t.mb[u] = ld(reinterpret_cast<const M*>(a.mask) + mask_off + i, a.nt_load);
+    if (MK == CURL_MASK_F32) t.mf[u] = ld(reinterpret_cast<const T*>(a.mask) + mask_off + i, a.nt_load);
+  }
+}
+
+template <class Op, int VEC, int U, int MK>
+__device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const StreamArgs& a,
+                                              typename Pack<VEC>::T* q0, size_t plane, unsigned base,
+                                              const typename Op::K& k) {
+  typedef typename Pack<VEC>::T T;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * 256u;
+    T y0, y1, y2;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float m = 1.0f;
+      if (MK == CURL_MASK_U8) m = mlane(t.mb[u], e);
+      if (MK == CURL_MASK_F32) m = lane(t.mf[u], e);
+      Px o = Op::apply(Px{lane(t.x0[u], e), lane(t.x1[u], e), lane(t.x2[u], e)}, m, k);
+      set_lane(y0, e, o.c0);
+      set_lane(y1, e, o.c1);
+      set_lane(y2, e, o.c2);
+    }
+    if (i < a.n) {
+      st(q0 + i, y0, a.nt_store);
+      st(q0 + plane + i, y1, a.nt_store);
+      st(q0 + 2 * plane + i, y2, a.nt_store);
+    }
+  }
+}
+
+template <class Op, int VEC, int U, int MK>
+__global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
+  typedef typename Pack<VEC>::T T;
   const unsigned bid = remap_block(blockIdx.x, a.n_blocks, a.xcd_remap);
   const unsigned img = bid / a.blocks_per_image;
   const unsigned chunk = bid - img * a.blocks_per_image;
@@ -185,50 +239,11 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
   const size_t plane = (size_t)a.n;
   const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
   T* q0 = reinterpret_cast<T*>(a.out) + (size_t)img * 3 * plane;
+  const size_t mask_off = (size_t)img * plane;
   const unsigned base = chunk * (256u * U) + threadIdx.x;
-
-  T x0[U], x1[U], x2[U];
-  T mf[U];
-  M mb[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    unsigned i = base + u * 256u;
-    if (i < a.n) {
-      x0[u] = ld(p0 + i, a.nt_load);
-      x1[u] = ld(p0 + plane + i, a.nt_load);
-      x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
-      if (Op::kMask) {
-        if (a.mask_kind == CURL_MASK_U8)
-          mb[u] = ld(reinterpret_cast<const M*>(a.mask) + (size_t)img * plane + i, a.nt_load);
-        else if (a.mask_kind == CURL_MASK_F32)
-          mf[u] = ld(reinterpret_cast<const T*>(a.mask) + (size_t)img * plane + i, a.nt_load);
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    unsigned i = base + u * 256u;
-    if (i < a.n) {
-      T y0, y1, y2;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float m = 1.0f;
-        if (Op::kMask) {
-          if (a.mask_kind == CURL_MASK_U8)
-            m = mlane(mb[u], e);
-          else if (a.mask_kind == CURL_MASK_F32)
-            m = lane(mf[u], e);
-        }
-        Px o = Op::apply(Px{lane(x0[u], e), lane(x1[u], e), lane(x2[u], e)}, m, k);
-        set_lane(y0, e, o.c0);
-        set_lane(y1, e, o.c1);
-        set_lane(y2, e, o.c2);
-      }
-      st(q0 + i, y0, a.nt_store);
-      st(q0 + plane + i, y1, a.nt_store);
-      st(q0 + 2 * plane + i, y2, a.nt_store);
-    }
-  }
+  Tile<VEC, U, MK> t;
+  load_tile(t, a, p0, plane, mask_off, base);
+  compute_store<Op, VEC, U, MK>(t, a, q0, plane, base, k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,8 +484,8 @@ struct Geometry {
   int nt_load, nt_store, xcd;
 };
 
-// Library defaults chosen from the sweep in DESIGN.md (profiles/): float4, 2 groups per lane.
-#define DEFAULT_UNROLL 2
+// Library defaults chosen from the sweep in DESIGN.md (profiles/).
+#define DEFAULT_UNROLL 1
 #define DEFAULT_NT_LOAD 0
 #define DEFAULT_NT_STORE 0
 
@@ -486,8 +501,8 @@ static int make_geometry(Geometry& g, const void* p0, const void* p1, const void
   if (u != 1 && u != 2 && u != 4) return fail(CURL_E_FLAGS, "tuning unroll must be 1, 2 or 4");
   g.unroll = u;
   g.n = (unsigned)(HW / g.vec);
-  unsigned per_block = 256u * (unsigned)u;
-  g.blocks_per_image = (g.n + per_block - 1) / per_block;
+  unsigned per_chunk = 256u * (unsigned)u;
+  g.blocks_per_image = (g.n + per_chunk - 1) / per_chunk;
   uint64_t nb = (uint64_t)g.blocks_per_image * (uint64_t)B;
   if (nb > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
   g.n_blocks = (unsigned)nb;
@@ -498,21 +513,26 @@ static int make_geometry(Geometry& g, const void* p0, const void* p1, const void
   return 0;
 }
 
-template <class Op, int VEC>
+template <class Op, int VEC, int MK>
 static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s) {
   dim3 grid(g.n_blocks), block(256);
   switch (g.unroll) {
     case 1:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 1>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK>), grid, block, 0, s, a);
       break;
     case 2:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 2>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 2, MK>), grid, block, 0, s, a);
       break;
     default:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 4>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 4, MK>), grid, block, 0, s, a);
       break;
   }
   return hipGetLastError();
+}
+
+template <class Op, int MK>
+static hipError_t launch_v(const Geometry& g, const StreamArgs& a, hipStream_t s) {
+  return (g.vec == 4) ? launch_u<Op, 4, MK>(g, a, s) : launch_u<Op, 1, MK>(g, a, s);
 }
 
 template <class Op>
@@ -529,11 +549,17 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.n = g.n;
   a.blocks_per_image = g.blocks_per_image;
   a.n_blocks = g.n_blocks;
-  a.mask_kind = mask_kind;
   a.nt_load = g.nt_load;
   a.nt_store = g.nt_store;
   a.xcd_remap = g.xcd;
-  hipError_t e = (g.vec == 4) ? launch_u<Op, 4>(g, a, s) : launch_u<Op, 1>(g, a, s);
+  hipError_t e;
+  if constexpr (Op::kMask) {
+    e = (mask_kind == CURL_MASK_U8)    ? launch_v<Op, CURL_MASK_U8>(g, a, s)
+        : (mask_kind == CURL_MASK_F32) ? launch_v<Op, CURL_MASK_F32>(g, a, s)
+                                       : launch_v<Op, CURL_MASK_NONE>(g, a, s);
+  } else {
+    e = launch_v<Op, CURL_MASK_NONE>(g, a, s);
+  }
   if (e != hipSuccess) return hip_fail(e, name);
   return 0;
 }

@@ -57,6 +57,36 @@ CURL_HD float clampf(float x, float lo, float hi) {
 }
 CURL_HD float clamp01(float x) { return clampf(x, 0.0f, 1.0f); }
 
+// ---------------------------------------------------------------- branch-free selects
+// Measured on MI355X (tools/ubench/valu_rate.hip): v_cndmask_b32 with its mask in VCC -- what hipcc emits
+// for `c ? a : b` -- issues once per ~23 cycles per SIMD, against 2 for v_fma/v_mul/v_add/shift/and/or and
+// ~3.5 for v_bfi/v_max/v_med3/v_cmp.  The fused kernels held ~17 such selects per pixel (36 % of their
+// VALU time), so every select here is built from the sign bit instead: subtract, arithmetic shift, bitwise
+// blend.  A bitwise blend also discards a NaN/garbage value in the branch not taken, which is what lets the
+// `clamp(min=1e-4)` guards in front of the reference's pow() calls go (they only protect dead branches).
+CURL_HD int f2i(float x) { return __builtin_bit_cast(int, x); }
+CURL_HD float i2f(int x) { return __builtin_bit_cast(float, x); }
+// Keeps the optimiser from folding `mask & a | ~mask & b` back into compare + v_cndmask.
+CURL_HD int opaque(int m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(m));
+#endif
+  return m;
+}
+CURL_HD int neg_mask(float x) { return opaque(f2i(x) >> 31); }           // all ones iff sign bit set
+CURL_HD int zero_mask(float t) { return opaque((f2i(t) - 1) >> 31); }    // t >= +0: all ones iff t == +0
+CURL_HD int nonzero_mask(float t) { return opaque((-f2i(t)) >> 31); }    // t >= +0: all ones iff t > 0
+CURL_HD float blend(int mask, float a, float b) {  // mask ? a : b, bit by bit
+#if defined(__HIP_DEVICE_COMPILE__)
+  return i2f(__builtin_amdgcn_bitop3_b32(mask, f2i(a), f2i(b), 0xCA));  // v_bitop3_b32 (gfx950), one instruction
+#else
+  return i2f((mask & f2i(a)) | (~mask & f2i(b)));
+#endif
+}
+CURL_HD float keep_if(int mask, float a) { return i2f(mask & f2i(a)); }                             // mask ? a : +0
+// x <= thr ? a : b   (thr - x is exact-or-nonzero for x != thr: float32 denormals are on, hipcc default)
+CURL_HD float select_le(float x, float thr, float a, float b) { return blend(neg_mask(thr - x), b, a); }
+
 // ---------------------------------------------------------------- constants
 // colors.py:37-38 / 118-119
 constexpr float kSrgbThr = (float)0.04045;
@@ -97,24 +127,25 @@ CURL_HD float cbrt_pos(float x) { return hw_exp2(kThird * hw_log2(x)); }
 
 // ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
 CURL_HD float srgb_to_linear(float x) {
-  // colors.py:37-38: both branches are evaluated and blended with 0/1 masks in the reference;
-  // a select gives the same value (the dead branch is finite, so it only adds +0).
+  // colors.py:37-38: both branches are evaluated and blended with 0/1 masks in the reference.  The gamma
+  // branch is taken only for x > 0.04045, where clamp(x, min=1e-4) is the identity, so the guard is dropped.
   float lin = x * kInv1292;
-  float gam = pow_gamma((fmaxf(x, kFloor) + 0.055f) * kInv1055);
-  return (x <= kSrgbThr) ? lin : gam;
+  float gam = pow_gamma(fmaf(x, kInv1055, (float)(0.055 / 1.055)));
+  return select_le(x, kSrgbThr, lin, gam);
 }
 CURL_HD float lab_f(float t) {
-  // colors.py:45-47
+  // colors.py:45-47 (cube root taken only for t > eps^3 > 1e-4)
   float lin = fmaf(t, kInv3Eps2, k4_29);
-  float cub = cbrt_pos(fmaxf(t, kFloor));
-  return (t <= kEps3) ? lin : cub;
+  float cub = cbrt_pos(t);
+  return select_le(t, kEps3, lin, cub);
 }
 CURL_HD Px rgb2lab(Px p) {
   float r = srgb_to_linear(p.c0), g = srgb_to_linear(p.c1), b = srgb_to_linear(p.c2);
   // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white)
-  float X = fmaf(0.180423f, b, fmaf(0.357580f, g, 0.412453f * r)) * kInvXn;
+  // (the 1/white factors are folded into the matrix rows: one rounding fewer per entry, 2 multiplies saved)
+  float X = fmaf(0.180423f * kInvXn, b, fmaf(0.357580f * kInvXn, g, (0.412453f * kInvXn) * r));
   float Y = fmaf(0.072169f, b, fmaf(0.715160f, g, 0.212671f * r));
-  float Z = fmaf(0.950227f, b, fmaf(0.119193f, g, 0.019334f * r)) * kInvZn;
+  float Z = fmaf(0.950227f * kInvZn, b, fmaf(0.119193f * kInvZn, g, (0.019334f * kInvZn) * r));
   float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
   // colors.py:18-20,50: L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz);
   // colors.py:57-59: L/100, (a/110 + 1)/2, (b/110 + 1)/2 -- constants folded.
@@ -127,33 +158,28 @@ CURL_HD Px rgb2lab(Px p) {
 
 // ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
 CURL_HD float lab_finv(float f) {
-  // colors.py:110-111 ; x**3.0 is x*x*x in torch
-  float lin = k3Eps2 * (f - k4_29);
-  float c = fmaxf(f, kFloor);
-  float cub = c * c * c;
-  return (f <= kEps) ? lin : cub;
+  // colors.py:110-111 ; x**3.0 is x*x*x in torch (cube taken only for f > eps > 1e-4)
+  float lin = fmaf(f, k3Eps2, -(k3Eps2 * k4_29));
+  float cub = f * f * f;
+  return select_le(f, kEps, lin, cub);
 }
 CURL_HD float linear_to_srgb(float v) {
-  // colors.py:118-119
+  // colors.py:118-119 (power taken only for v > 0.0031308 > 1e-4)
   float lin = v * 12.92f;
-  float gam = fmaf(pow_inv_gamma(fmaxf(v, kFloor)), 1.055f, -0.055f);
-  return (v <= kLinThr) ? lin : gam;
+  float gam = fmaf(pow_inv_gamma(v), 1.055f, -0.055f);
+  return select_le(v, kLinThr, lin, gam);
 }
 CURL_HD Px lab2rgb(Px p) {
-  // colors.py:97-99
-  float L = p.c0 * 100.0f;
-  float a = fmaf(p.c1, 2.0f, -1.0f) * 110.0f;
-  float b = fmaf(p.c2, 2.0f, -1.0f) * 110.0f;
-  // colors.py:79-81,104-106 with the float32 constants 1/116, 1/500, -1/200
-  float fy = (L + 16.0f) * (float)(1 / 116.0);
-  float fx = fmaf(a, (float)(1 / 500.0), fy);
-  float fz = fmaf(b, (float)(-1 / 200.0), fy);
-  // colors.py:114
-  float X = lab_finv(fx) * kXn, Y = lab_finv(fy), Z = lab_finv(fz) * kZn;
-  // colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
-  float r = fmaf(-0.4985314f, Z, fmaf(-1.5371385f, Y, 3.2404542f * X));
-  float g = fmaf(0.0415560f, Z, fmaf(1.8760108f, Y, -0.9692660f * X));
-  float bb = fmaf(1.0572252f, Z, fmaf(-0.2040259f, Y, 0.0556434f * X));
+  // colors.py:97-99 (L*100, (a*2-1)*110, (b*2-1)*110) and colors.py:79-81,104-106
+  // (fy = (L+16)/116, fx = fy + a/500, fz = fy - b/200) with the constants folded:
+  float fy = fmaf(p.c0, (float)(100.0 / 116.0), (float)(16.0 / 116.0));
+  float fx = fmaf(p.c1, (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0));
+  float fz = fmaf(p.c2, (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0));
+  // colors.py:114 (x white) folded into the columns of colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
+  float X = lab_finv(fx), Y = lab_finv(fy), Z = lab_finv(fz);
+  float r = fmaf(-0.4985314f * kZn, Z, fmaf(-1.5371385f, Y, (3.2404542f * kXn) * X));
+  float g = fmaf(0.0415560f * kZn, Z, fmaf(1.8760108f, Y, (-0.9692660f * kXn) * X));
+  float bb = fmaf(1.0572252f * kZn, Z, fmaf(-0.2040259f, Y, (0.0556434f * kXn) * X));
   Px o;
   o.c0 = linear_to_srgb(r);
   o.c1 = linear_to_srgb(g);
@@ -167,15 +193,15 @@ CURL_HD Px rgb2hsv(Px p) {
   float mx = fmaxf(r, fmaxf(g, b));
   float mn = fminf(r, fminf(g, b));
   float df = mx - mn;
-  float dfi = rcp_refined(df);  // unused (selected away) when df == 0
-  // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum
-  float t0 = (r == mx) ? (g - b) * dfi : 0.0f;
-  float t1 = (g == mx) ? fmaf(b - r, dfi, 2.0f) : 0.0f;
-  float t2 = (b == mx) ? fmaf(r - g, dfi, 4.0f) : 0.0f;
-  float h = (df == 0.0f) ? 0.0f : (t0 + t1) + t2;
-  h = h * 60.0f;                        // colors.py:225
-  h = (h < 0.0f) ? h + 360.0f : h;      // colors.py:228-229
-  h = h * (float)(1.0 / 360.0);         // colors.py:231
+  float dfi = rcp_refined(df);  // inf/NaN when df == 0: masked below
+  // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum.
+  // [c == mx] as a bit mask: mx - c is +0 exactly when they are equal.
+  float t0 = keep_if(zero_mask(mx - r), (g - b) * dfi);
+  float t1 = keep_if(zero_mask(mx - g), fmaf(b - r, dfi, 2.0f));
+  float t2 = keep_if(zero_mask(mx - b), fmaf(r - g, dfi, 4.0f));
+  float h = keep_if(nonzero_mask(df), (t0 + t1) + t2);  // df == 0 -> 0 (colors.py:221)
+  // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
+  h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
   float s = df * rcp_refined(mx);       // colors.py:234-237 (mx >= 1e-9 > 0 after the clamp)
   Px o;
   o.c0 = clampf(h, kHsvFloor, 1.0f);    // colors.py:240
@@ -186,15 +212,15 @@ CURL_HD Px rgb2hsv(Px p) {
 
 // ---------------------------------------------------------------- HSV -> RGB   colors.py:131-177
 CURL_HD Px hsv2rgb(Px p) {
-  float h = clamp01(p.c0) * 360.0f, s = clamp01(p.c1), v = clamp01(p.c2);
+  // colors.py:141-175 in sextant units: clamp(360h - a, 0, 60) * (d/60) == clamp(6h - a/60, 0, 1) * d,
+  // so every ramp is one saturating add (v_add_f32 ... clamp) and the /60 disappears.
+  float h = clamp01(p.c0) * 6.0f, s = clamp01(p.c1), v = clamp01(p.c2);
   float q = v * (1.0f - s);
-  const float k60 = (float)(1.0 / 60.0);
-  float up = (v - q) * k60;   // colors.py:153,163
-  float dn = (q - v) * k60;   // colors.py:144
+  float d = v - q;
   // the reference's identically-zero terms (m1,m3,m5 = 0) add +0 and are dropped
-  float r = v + clampf(h - 60.0f, 0.0f, 60.0f) * dn + clampf(h - 240.0f, 0.0f, 60.0f) * (-dn);
-  float g = q + clampf(h, 0.0f, 60.0f) * up + clampf(h - 180.0f, 0.0f, 60.0f) * (-up);
-  float b = q + clampf(h - 120.0f, 0.0f, 60.0f) * up + clampf(h - 300.0f, 0.0f, 60.0f) * (-up);
+  float r = fmaf(clamp01(h - 4.0f), d, fmaf(clamp01(h - 1.0f), -d, v));   // colors.py:144-150
+  float g = fmaf(clamp01(h - 3.0f), -d, fmaf(clamp01(h), d, q));          // colors.py:153-159
+  float b = fmaf(clamp01(h - 5.0f), -d, fmaf(clamp01(h - 2.0f), d, q));   // colors.py:163-168
   Px o;
   o.c0 = clamp01(r);
   o.c1 = clamp01(g);
