@@ -19,6 +19,7 @@ F_TUNE_NT_LOAD = 0x1000
 F_TUNE_NT_STORE = 0x2000
 F_TUNE_XCD_REMAP = 0x4000
 F_TUNE_NO_NT = 0x8000
+F_DIAG_NO_MEM = 0x10000
 MAX_KNOTS = 256
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers

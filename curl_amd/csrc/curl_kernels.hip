@@ -38,10 +38,12 @@ static int hip_fail(hipError_t e, const char* where) {
 // workspace layout (floats, per image)
 //   [0..19]  (a,b) of curve c at [2c],[2c+1]   (segment order: see prep kernel)
 //   [20..22] regulariser of segment 0,1,2 ; [23] total
+//   [24..26] lab2rgb(0,0,0): what the Lab stage yields where the mask is 0 (model.py:154-157)
 //   [32..)   exp'd knots of every curve, segment after segment
 // ------------------------------------------------------------------------------------------------
 #define WS_COEF 0
 #define WS_REG 20
+#define WS_MASKED 24
 #define WS_KNOTS 32
 #define MAX_CURVES 10
 
@@ -108,6 +110,10 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     tot = (seg_reg[0] + seg_reg[1]) + seg_reg[2];  // model.py:172-174 (rgb + lab) + hsv
     ws[WS_REG + 3] = tot;
     if (a.reg_out) a.reg_out[b] = tot;
+    Px z = lab_stage_masked_out();
+    ws[WS_MASKED + 0] = z.c0;
+    ws[WS_MASKED + 1] = z.c1;
+    ws[WS_MASKED + 2] = z.c2;
   }
 }
 
@@ -127,6 +133,7 @@ struct StreamArgs {
   unsigned blocks_per_image;  // chunks per image
   unsigned n_blocks;          // total
   int nt_load, nt_store, xcd_remap;
+  int no_mem;  // diagnostics: synthesise inputs, suppress stores (VALU-only timing; results undefined)
 };
 
 template <int VEC>
@@ -194,6 +201,15 @@ __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs&
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     unsigned i = min(base + u * 256u, a.n - 1u);
+    if (a.no_mem) {
+      float f = (float)(i & 1023u) * (1.0f / 1024.0f);
+      t.x0[u] = T(f);
+      t.x1[u] = T(1.0f - f);
+      t.x2[u] = T(0.5f * f + 0.1f);
+      if (MK == CURL_MASK_U8) t.mb[u] = typename Pack<VEC>::M(1);
+      if (MK == CURL_MASK_F32) t.mf[u] = T(1.0f);
+      continue;
+    }
     t.x0[u] = ld(p0 + i, a.nt_load);
     t.x1[u] = ld(p0 + plane + i, a.nt_load);
     t.x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
@@ -207,21 +223,58 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
                                               typename Pack<VEC>::T* q0, size_t plane, unsigned base,
                                               const typename Op::K& k) {
   typedef typename Pack<VEC>::T T;
+  constexpr bool kBinary = (MK != CURL_MASK_F32);  // none / bool / uint8: the mask is exactly 0 or 1
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     unsigned i = base + u * 256u;
     T y0, y1, y2;
+    bool live = true;
+    if (Op::kMask && MK != CURL_MASK_NONE) {
+      // Masks are foreground masks: whole waves are often masked out.  Where every lane of the wave has
+      // m == 0 for all its pixels the result is a constant (0 for the layer, lab2rgb(0,0,0) for the Lab
+      // stage) and the arithmetic is skipped -- a wave-uniform branch (ballot), no divergence.
+      bool lane_live = false;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float m = 1.0f;
-      if (MK == CURL_MASK_U8) m = mlane(t.mb[u], e);
-      if (MK == CURL_MASK_F32) m = lane(t.mf[u], e);
-      Px o = Op::apply(Px{lane(t.x0[u], e), lane(t.x1[u], e), lane(t.x2[u], e)}, m, k);
-      set_lane(y0, e, o.c0);
-      set_lane(y1, e, o.c1);
-      set_lane(y2, e, o.c2);
+      for (int e = 0; e < VEC; ++e)
+        lane_live |= (MK == CURL_MASK_U8) ? (mlane(t.mb[u], e) != 0.0f) : (lane(t.mf[u], e) != 0.0f);
+      live = __builtin_amdgcn_ballot_w64(lane_live) != 0ull;
     }
-    if (i < a.n) {
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float m = 1.0f;
+        if (MK == CURL_MASK_U8) m = mlane(t.mb[u], e);
+        if (MK == CURL_MASK_F32) m = lane(t.mf[u], e);
+        Px o = Op::template apply<kBinary>(Px{lane(t.x0[u], e), lane(t.x1[u], e), lane(t.x2[u], e)}, m, k);
+        if (Op::kBlendMaskedOut && MK == CURL_MASK_U8) {
+          // the binary specialisation leaves m == 0 pixels to us: overwrite with the masked-out constant
+          Px z = Op::masked_out(k);
+          int keep = opaque(-(int)(m != 0.0f));
+          o.c0 = blend(keep, o.c0, z.c0);
+          o.c1 = blend(keep, o.c1, z.c1);
+          o.c2 = blend(keep, o.c2, z.c2);
+        }
+        set_lane(y0, e, o.c0);
+        set_lane(y1, e, o.c1);
+        set_lane(y2, e, o.c2);
+      }
+    } else {
+      Px z = Op::masked_out(k);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        set_lane(y0, e, z.c0);
+        set_lane(y1, e, z.c1);
+        set_lane(y2, e, z.c2);
+      }
+    }
+    bool keep = true;
+    if (a.no_mem) {  // every output feeds the (never true) condition, so nothing can be sunk or dropped
+      float chk = 0.0f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) chk += lane(y0, e) + lane(y1, e) + lane(y2, e);
+      keep = (chk == -123.0f);
+    }
+    if (i < a.n && keep) {
       st(q0 + i, y0, a.nt_store);
       st(q0 + plane + i, y1, a.nt_store);
       st(q0 + 2 * plane + i, y2, a.nt_store);
@@ -250,12 +303,16 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
 // ops
 // ------------------------------------------------------------------------------------------------
 struct NoK {};
-#define CONVERTER_OP(NAME, FN)                                               \
-  struct NAME {                                                              \
-    typedef NoK K;                                                           \
-    static constexpr bool kMask = false;                                     \
-    static __device__ __forceinline__ K load(const float*) { return K{}; }   \
-    static __device__ __forceinline__ Px apply(Px p, float, const K&) { return FN(p); } \
+#define CONVERTER_OP(NAME, FN)                                                           \
+  struct NAME {                                                                          \
+    typedef NoK K;                                                                       \
+    static constexpr bool kMask = false;                                                 \
+    static constexpr int kUnroll = 2;                                                    \
+    static __device__ __forceinline__ K load(const float*) { return K{}; }               \
+    template <bool>                                                                      \
+    static __device__ __forceinline__ Px apply(Px p, float, const K&) { return FN(p); }  \
+    static constexpr bool kBlendMaskedOut = false;                                       \
+    static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; } \
   };
 CONVERTER_OP(OpRgb2Lab, rgb2lab)
 CONVERTER_OP(OpLab2Rgb, lab2rgb)
@@ -271,45 +328,60 @@ struct OpAdjust3 {  // adjust_rgb / adjust_lab, affine form
     Affine k[3];
   };
   static constexpr bool kMask = false;
+  static constexpr int kUnroll = 2;
   static __device__ __forceinline__ K load(const float* ws) {
     K k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
     return k;
   }
+  template <bool>
   static __device__ __forceinline__ Px apply(Px p, float, const K& k) { return adjust3(p, k.k[0], k.k[1], k.k[2]); }
+  static constexpr bool kBlendMaskedOut = false;
+  static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
 struct OpAdjustHsv {
   struct K {
     Affine k[4];
   };
   static constexpr bool kMask = false;
+  static constexpr int kUnroll = 2;
   static __device__ __forceinline__ K load(const float* ws) {
     K k;
 #pragma unroll
     for (int c = 0; c < 4; ++c) k.k[c] = load_affine(ws, c);
     return k;
   }
+  template <bool>
   static __device__ __forceinline__ Px apply(Px p, float, const K& k) {
     return adjust_hsv4(p, k.k[0], k.k[1], k.k[2], k.k[3]);
   }
+  static constexpr bool kBlendMaskedOut = false;
+  static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
 struct OpLabStage {
   struct K {
     Affine k[3];
+    Px masked;
   };
   static constexpr bool kMask = true;
+  static constexpr int kUnroll = 1;  // arithmetic-heavy: occupancy beats per-lane ILP (profiles/sweep_r01.md)
   static __device__ __forceinline__ K load(const float* ws) {
     K k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
+    k.masked = Px{ws[WS_MASKED], ws[WS_MASKED + 1], ws[WS_MASKED + 2]};
     return k;
   }
-  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return lab_stage(p, m, k.k); }
+  template <bool BINARY>
+  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return lab_stage<BINARY>(p, m, k.k); }
+  static constexpr bool kBlendMaskedOut = true;  // lab_stage<true> computes m == 0 pixels as if m == 1
+  static __device__ __forceinline__ Px masked_out(const K& k) { return k.masked; }
 };
 struct OpLayer {
   typedef LayerCoef K;
   static constexpr bool kMask = true;
+  static constexpr int kUnroll = 1;
   static __device__ __forceinline__ K load(const float* ws) {
     K k;
 #pragma unroll
@@ -320,7 +392,10 @@ struct OpLayer {
     for (int c = 0; c < 4; ++c) k.hsv[c] = load_affine(ws, 6 + c);
     return k;
   }
-  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return curl_layer(p, m, k); }
+  template <bool BINARY>
+  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return curl_layer<BINARY>(p, m, k); }
+  static constexpr bool kBlendMaskedOut = false;  // curl_layer ends in `* m` for every mask kind
+  static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -469,7 +544,7 @@ static int check_img(const void* in, const void* out, int B, int H, int W) {
 }
 static int check_flags(unsigned flags, unsigned allowed) {
   const unsigned tune = CURL_F_TUNE_UNROLL_MASK | CURL_F_TUNE_NT_LOAD | CURL_F_TUNE_NT_STORE |
-                        CURL_F_TUNE_XCD_REMAP | CURL_F_TUNE_NO_NT;
+                        CURL_F_TUNE_XCD_REMAP | CURL_F_TUNE_NO_NT | CURL_F_DIAG_NO_MEM;
   if (flags & ~(allowed | tune)) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point");
   if ((flags & CURL_F_EXACT_ORDER) && (flags & CURL_F_PWL))
     return fail(CURL_E_FLAGS, "CURL_F_EXACT_ORDER and CURL_F_PWL are exclusive");
@@ -485,19 +560,18 @@ struct Geometry {
 };
 
 // Library defaults chosen from the sweep in DESIGN.md (profiles/).
-#define DEFAULT_UNROLL 1
 #define DEFAULT_NT_LOAD 0
 #define DEFAULT_NT_STORE 0
 
 static int make_geometry(Geometry& g, const void* p0, const void* p1, const void* pm, int mask_kind, int B, int H, int W,
-                         unsigned flags) {
+                         unsigned flags, int default_unroll) {
   size_t HW = (size_t)H * W;
   bool aligned = (HW % 4 == 0) && (((uintptr_t)p0 | (uintptr_t)p1) % 16 == 0);
   if (pm && mask_kind == CURL_MASK_F32 && ((uintptr_t)pm % 16)) aligned = false;
   if (pm && mask_kind == CURL_MASK_U8 && ((uintptr_t)pm % 4)) aligned = false;
   g.vec = aligned ? 4 : 1;
   int u = (int)((flags & CURL_F_TUNE_UNROLL_MASK) >> CURL_F_TUNE_UNROLL_SHIFT);
-  if (u == 0) u = DEFAULT_UNROLL;
+  if (u == 0) u = default_unroll;
   if (u != 1 && u != 2 && u != 4) return fail(CURL_E_FLAGS, "tuning unroll must be 1, 2 or 4");
   g.unroll = u;
   g.n = (unsigned)(HW / g.vec);
@@ -539,7 +613,7 @@ template <class Op>
 static int launch_stream(const float* in, float* out, const void* mask, int mask_kind, const float* coef,
                          unsigned coef_stride, int B, int H, int W, unsigned flags, hipStream_t s, const char* name) {
   Geometry g;
-  if (int rc = make_geometry(g, in, out, mask, mask_kind, B, H, W, flags)) return rc;
+  if (int rc = make_geometry(g, in, out, mask, mask_kind, B, H, W, flags, Op::kUnroll)) return rc;
   StreamArgs a;
   a.in = in;
   a.out = out;
@@ -552,6 +626,7 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.nt_load = g.nt_load;
   a.nt_store = g.nt_store;
   a.xcd_remap = g.xcd;
+  a.no_mem = (flags & CURL_F_DIAG_NO_MEM) ? 1 : 0;
   hipError_t e;
   if constexpr (Op::kMask) {
     e = (mask_kind == CURL_MASK_U8)    ? launch_v<Op, CURL_MASK_U8>(g, a, s)
@@ -623,7 +698,7 @@ static int launch_chain(const float* in, float* out, const float* knots, unsigne
                         const int* knot_off, const int* cin, const int* cout, int mode, int B, int H, int W,
                         unsigned flags, hipStream_t s) {
   Geometry g;
-  if (int rc = make_geometry(g, in, out, nullptr, 0, B, H, W, flags)) return rc;
+  if (int rc = make_geometry(g, in, out, nullptr, 0, B, H, W, flags, 2)) return rc;
   ChainArgs a;
   a.in = in;
   a.out = out;

@@ -331,25 +331,40 @@ struct LayerCoef {
 };
 
 // model.py:151-157 : rgb2lab -> adjust_lab -> *mask -> lab2rgb
+// BINARY = the mask is known to be exactly 0 or 1 (bool / uint8 masks, or no mask at all): x*1 == x, so the
+// multiply is dropped for m == 1, and pixels with m == 0 are finished by the caller (lab_stage_masked_out).
+template <bool BINARY>
 CURL_HD Px lab_stage(Px in, float m, const Affine* k) {
   Px lab = adjust3(rgb2lab(in), k[0], k[1], k[2]);
-  lab.c0 *= m;
-  lab.c1 *= m;
-  lab.c2 *= m;
+  if (!BINARY) {
+    lab.c0 *= m;
+    lab.c1 *= m;
+    lab.c2 *= m;
+  }
   return lab2rgb(lab);
 }
+// what model.py:154-157 yields where the mask is 0: lab2rgb(0,0,0), the same colour for every such pixel
+CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }
 
-// model.py:137-176 minus the dead `feat` lines
+// model.py:137-176 minus the dead `feat` lines.  For a BINARY mask every intermediate `* mask`
+// (model.py:154,160,166) is the identity where m == 1, and where m == 0 the result is 0 whatever the
+// intermediates were (every stage maps finite values to finite values and model.py:170 ends in `* mask`),
+// so only the final multiply is kept.
+template <bool BINARY>
 CURL_HD Px curl_layer(Px in, float m, const LayerCoef& k) {
-  Px rgb = lab_stage(in, m, k.lab);
+  Px rgb = lab_stage<BINARY>(in, m, k.lab);
   rgb = adjust3(rgb, k.rgb[0], k.rgb[1], k.rgb[2]);  // model.py:159
-  rgb.c0 *= m;                                       // model.py:160
-  rgb.c1 *= m;
-  rgb.c2 *= m;
+  if (!BINARY) {
+    rgb.c0 *= m;                                     // model.py:160
+    rgb.c1 *= m;
+    rgb.c2 *= m;
+  }
   Px hsv = adjust_hsv4(rgb2hsv(rgb), k.hsv[0], k.hsv[1], k.hsv[2], k.hsv[3]);  // model.py:163-165
-  hsv.c0 *= m;                                       // model.py:166
-  hsv.c1 *= m;
-  hsv.c2 *= m;
+  if (!BINARY) {
+    hsv.c0 *= m;                                     // model.py:166
+    hsv.c1 *= m;
+    hsv.c2 *= m;
+  }
   Px res = hsv2rgb(hsv);                             // model.py:169
   Px o;
   o.c0 = clamp01(in.c0 + res.c0) * m;                // model.py:170

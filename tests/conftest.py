@@ -95,13 +95,13 @@ def twin():
             return out, reg
 
         @staticmethod
-        def layer(stage, img, mask, L, R, H):
+        def layer(stage, img, mask, L, R, H, binary=False):
             img, mask, L, R, H = f32(img), f32(mask), f32(L), f32(R), f32(H)
             out = np.empty_like(img)
             B, _, Hh, W = img.shape
             reg = np.empty(B, np.float32)
             lib.twin_layer(stage, P(img), P(mask), P(L), P(R), P(H), P(out), P(reg), B, ctypes.c_long(Hh * W),
-                           L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4)
+                           L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4, int(binary))
             return out, reg
 
     return Twin

@@ -84,6 +84,10 @@ def test_layer_sigma01(twin, golden):
             np.testing.assert_allclose(reg, c[key + "_reg"], rtol=2e-6)
             ls, _ = twin.layer(0, c[inn], m, L, R, H)
             assert max_err(ls, c[key + "_lab_stage"]) <= 1e-5, key
+            if mk != "soft":  # 0/1 masks: the binary-mask specialisation (skipped multiplies, masked-out shortcut)
+                outb, _ = twin.layer(1, c[inn], m, L, R, H, binary=True)
+                lsb, _ = twin.layer(0, c[inn], m, L, R, H, binary=True)
+                assert np.array_equal(outb, out) and np.array_equal(lsb, ls), key
 
 
 def test_layer_error_is_reference_noise_sized(twin):

@@ -104,8 +104,9 @@ int twin_adjust(int ncurves, const float* img, const float* raw, float* out, flo
 }
 
 // stage 0: lab_stage (rawR/rawH ignored), 1: full layer.  mask: float [B,HW] or NULL.
+// binary != 0: run the binary-mask specialisation (mask values must be 0 or 1), incl. the masked-out shortcut.
 int twin_layer(int stage, const float* img, const float* mask, const float* rawL, const float* rawR,
-               const float* rawH, float* out, float* reg, int B, long HW, int Kl, int Kr, int Kh) {
+               const float* rawH, float* out, float* reg, int B, long HW, int Kl, int Kr, int Kh, int binary) {
   std::vector<float> knots(4 * 256);
   for (int b = 0; b < B; ++b) {
     LayerCoef k;
@@ -120,7 +121,13 @@ int twin_layer(int stage, const float* img, const float* mask, const float* rawL
       const float* p = img + (size_t)b * 3 * HW + i;
       float m = mask ? mask[(size_t)b * HW + i] : 1.0f;
       Px x{p[0], p[HW], p[2 * HW]};
-      Px y = stage == 0 ? lab_stage(x, m, k.lab) : curl_layer(x, m, k);
+      Px y;
+      if (binary && m == 0.0f)
+        y = stage == 0 ? lab_stage_masked_out() : Px{0.0f, 0.0f, 0.0f};
+      else if (binary)
+        y = stage == 0 ? lab_stage<true>(x, m, k.lab) : curl_layer<true>(x, m, k);
+      else
+        y = stage == 0 ? lab_stage<false>(x, m, k.lab) : curl_layer<false>(x, m, k);
       float* q = out + (size_t)b * 3 * HW + i;
       q[0] = y.c0, q[HW] = y.c1, q[2 * HW] = y.c2;
     }
