@@ -112,3 +112,20 @@ def test_layer_error_is_reference_noise_sized(twin):
         assert tw_noise.mean() <= 1.5 * ref_noise.mean() + 1e-8
         d = np.abs(tw - o32.numpy())
         assert (d > 1e-5).mean() < 2e-4 and d.max() < 1e-4
+
+
+def test_reference_sum_order_depends_on_shape(twin):
+    """Why 'bit-exact' carries a shape condition: ATen's sum kernel handles the last H*W mod 32 pixels of an
+    image outside its vector body, with a different accumulation order.  Exact-order mode reproduces the
+    vector-body order for EVERY pixel: identical bits where H*W % 32 == 0, 1-ulp-level noise elsewhere."""
+    for shape, must_match in (((2, 16, 24), True), ((1, 33, 64), True), ((2, 8, 8), True), ((2, 7, 9), False),
+                              ((3, 16, 17), False)):
+        B, H, W = shape
+        g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+        x = torch.rand(B, 3, H, W, generator=g) * 1.2 - 0.1
+        C = torch.exp(torch.randn(B, 16, generator=g) * 0.1)
+        ref = O.apply_curve(x, C, torch.zeros(B), 2, 0)[0].numpy()
+        out, _ = twin.apply_curve(x.numpy(), C.numpy(), None, 2, 0, mode=1)
+        if must_match:
+            assert np.array_equal(out, ref), shape
+        assert max_err(out, ref) <= 1e-6, shape
