@@ -16,7 +16,7 @@
 #include <string.h>
 
 #include "../../include/curl_hip.h"
-#include "curl_math.h"
+#include "curl_math_bwd.h"
 
 using namespace curlm;
 
@@ -502,6 +502,135 @@ __global__ void curve_reg_kernel(const float* C, float* reg, int B, int K) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward of the fused layer
+// ------------------------------------------------------------------------------------------------
+#define BWD_NACC 20  // P[10], Q[10]
+struct BwdArgs {
+  const float* in;
+  const float* gout;
+  float* gin;         // nullable
+  const void* mask;
+  const float* coef;  // workspace (prep output)
+  float* partial;     // [n_blocks][BWD_NACC] block partial sums of P,Q
+  unsigned coef_stride, n, blocks_per_image, n_blocks;
+};
+
+// One tile per block, like the forward.  Per-pixel reverse mode (curl_math_bwd.h) recomputes the forward
+// chain in registers; the 20 per-image curve sums are reduced wave -> LDS -> one row of `partial` per block
+// (no float atomics: the second pass sums the rows in a fixed order in float64, so results are reproducible).
+template <int VEC, int MK>
+__global__ __launch_bounds__(256) void layer_bwd_kernel(BwdArgs a) {
+  typedef typename Pack<VEC>::T T;
+  typedef typename Pack<VEC>::M M;
+  __shared__ float sPart[4][BWD_NACC];
+  const unsigned bid = blockIdx.x;
+  const unsigned img = bid / a.blocks_per_image;
+  const unsigned chunk = bid - img * a.blocks_per_image;
+  const LayerCoef k = OpLayer::load(a.coef + (size_t)img * a.coef_stride);
+  const size_t plane = (size_t)a.n;
+  const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
+  const T* g0 = reinterpret_cast<const T*>(a.gout) + (size_t)img * 3 * plane;
+  const unsigned i = chunk * 256u + threadIdx.x;
+  const unsigned ic = min(i, a.n - 1u);
+  const bool valid = i < a.n;
+  T x0 = p0[ic], x1 = p0[plane + ic], x2 = p0[2 * plane + ic];
+  T w0 = g0[ic], w1 = g0[plane + ic], w2 = g0[2 * plane + ic];
+  T mf;
+  M mb;
+  if (MK == CURL_MASK_U8) mb = reinterpret_cast<const M*>(a.mask)[(size_t)img * plane + ic];
+  if (MK == CURL_MASK_F32) mf = reinterpret_cast<const T*>(a.mask)[(size_t)img * plane + ic];
+  float acc[BWD_NACC];
+#pragma unroll
+  for (int c = 0; c < BWD_NACC; ++c) acc[c] = 0.0f;
+  T y0, y1, y2;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float m = 1.0f;
+    if (MK == CURL_MASK_U8) m = mlane(mb, e);
+    if (MK == CURL_MASK_F32) m = lane(mf, e);
+    if (!valid) m = 0.0f;  // lanes past the end contribute nothing (m multiplies every path to P, Q)
+    float P[10], Q[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) P[c] = Q[c] = 0.0f;
+    Px gi = curl_layer_bwd(Px{lane(x0, e), lane(x1, e), lane(x2, e)}, m, k, Px{lane(w0, e), lane(w1, e), lane(w2, e)},
+                           P, Q);
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      acc[c] += P[c];
+      acc[10 + c] += Q[c];
+    }
+    set_lane(y0, e, gi.c0);
+    set_lane(y1, e, gi.c1);
+    set_lane(y2, e, gi.c2);
+  }
+  if (a.gin && valid) {
+    T* q0 = reinterpret_cast<T*>(a.gin) + (size_t)img * 3 * plane;
+    q0[i] = y0;
+    q0[plane + i] = y1;
+    q0[2 * plane + i] = y2;
+  }
+  // wave64 butterfly, then the 4 waves through LDS
+#pragma unroll
+  for (int c = 0; c < BWD_NACC; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[c] = v;
+  }
+  const int wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+  if (lane_id == 0) {
+#pragma unroll
+    for (int c = 0; c < BWD_NACC; ++c) sPart[wave][c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < BWD_NACC) {
+    int c = threadIdx.x;
+    a.partial[(size_t)bid * BWD_NACC + c] = (sPart[0][c] + sPart[1][c]) + (sPart[2][c] + sPart[3][c]);
+  }
+}
+
+struct KnotsBwdArgs {
+  const float* ws;       // prep output (exp'd knots at WS_KNOTS)
+  const float* partial;  // [B][blocks_per_image][BWD_NACC]
+  const float* greg;     // nullable [B]
+  float* graw[3];        // gradients shaped like rawL, rawR, rawH
+  int K[3];
+  unsigned ws_stride, blocks_per_image;
+};
+
+// One block per image: fixed-order float64 reduction of the block partials, then the chain rule
+// (P, Q, d reg) -> raw knots of each of the 10 curves (curl_math_bwd.h: knots_bwd).
+__global__ __launch_bounds__(256) void knots_bwd_kernel(KnotsBwdArgs a) {
+  __shared__ double sAcc[256];
+  __shared__ double sPQ[BWD_NACC];
+  const unsigned b = blockIdx.x;
+  const float* part = a.partial + (size_t)b * a.blocks_per_image * BWD_NACC;
+  for (int c = 0; c < BWD_NACC; ++c) {
+    double v = 0.0;
+    for (unsigned i = threadIdx.x; i < a.blocks_per_image; i += 256) v += (double)part[(size_t)i * BWD_NACC + c];
+    sAcc[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sAcc[threadIdx.x] += sAcc[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sPQ[c] = sAcc[0];
+    __syncthreads();
+  }
+  const int c = threadIdx.x;
+  if (c < 10) {
+    int s = c < 3 ? 0 : (c < 6 ? 1 : 2);
+    int local = c - (s == 0 ? 0 : (s == 1 ? 3 : 6));
+    int K = a.K[s];
+    int off = (s == 0 ? 0 : (s == 1 ? 3 * a.K[0] : 3 * a.K[0] + 3 * a.K[1])) + local * K;
+    const float* C = a.ws + (size_t)b * a.ws_stride + WS_KNOTS + off;
+    int per_img = (s == 2 ? 4 : 3) * K;
+    float* g = a.graw[s] + (size_t)b * per_img + local * K;
+    knots_bwd(C, K, sPQ[c], sPQ[10 + c], a.greg ? (double)a.greg[b] : 0.0, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout edges: u8 HWC <-> f32 CHW
 // ------------------------------------------------------------------------------------------------
 // One thread per pixel; HWC bytes of a wave are one contiguous 192/256-byte run, CHW floats three
@@ -848,6 +977,84 @@ int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind, const 
   if (int rc = run_prep(rawL, 3, Kl, rawR, 3, Kr, rawH, 4, Kh, ws, stride, reg, B, s)) return rc;
   return launch_stream<OpLayer>(img, out, mask_kind ? mask : nullptr, mask_kind, ws, stride, B, H, W, flags, s,
                                 "curl_layer");
+}
+
+size_t curl_layer_bwd_scratch_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  size_t HW = (size_t)H * W;
+  size_t blocks = (HW + 255) / 256;  // upper bound: the scalar path, one pixel per lane
+  return (size_t)B * blocks * BWD_NACC * sizeof(float);
+}
+
+int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind, const float* rawL, const float* rawR,
+                       const float* rawH, const float* grad_out, const float* grad_reg, float* grad_img,
+                       float* grad_rawL, float* grad_rawR, float* grad_rawH, void* workspace, size_t workspace_bytes,
+                       void* scratch, size_t scratch_bytes, int B, int H, int W, int Kl, int Kr, int Kh, unsigned flags,
+                       curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, grad_out, B, H, W)) return rc;
+  if (!rawL || !rawR || !rawH) return fail(CURL_E_NULL, "rawL/rawR/rawH must all be non-NULL");
+  if (!grad_rawL || !grad_rawR || !grad_rawH) return fail(CURL_E_NULL, "grad_rawL/R/H must all be non-NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  if (int rc = check_K(Kl)) return rc;
+  if (int rc = check_K(Kr)) return rc;
+  if (int rc = check_K(Kh)) return rc;
+  if (int rc = check_flags(flags, 0)) return rc;
+  int n_knots = 3 * Kl + 3 * Kr + 4 * Kh;
+  if (int rc = check_ws(workspace, workspace_bytes, B, n_knots)) return rc;
+  if (!scratch || (uintptr_t)scratch % 16 || scratch_bytes < curl_layer_bwd_scratch_bytes(B, H, W))
+    return fail(CURL_E_WORKSPACE, "scratch missing, misaligned or smaller than curl_layer_bwd_scratch_bytes");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  unsigned stride = ws_stride(n_knots);
+  if (int rc = run_prep(rawL, 3, Kl, rawR, 3, Kr, rawH, 4, Kh, ws, stride, nullptr, B, s)) return rc;
+  size_t HW = (size_t)H * W;
+  bool aligned = (HW % 4 == 0) && (((uintptr_t)img | (uintptr_t)grad_out | (uintptr_t)grad_img) % 16 == 0);
+  if (mask_kind == CURL_MASK_F32 && ((uintptr_t)mask % 16)) aligned = false;
+  if (mask_kind == CURL_MASK_U8 && ((uintptr_t)mask % 4)) aligned = false;
+  BwdArgs a;
+  a.in = img;
+  a.gout = grad_out;
+  a.gin = grad_img;
+  a.mask = mask_kind ? mask : nullptr;
+  a.coef = ws;
+  a.partial = (float*)scratch;
+  a.coef_stride = stride;
+  a.n = (unsigned)(HW / (aligned ? 4 : 1));
+  a.blocks_per_image = (a.n + 255u) / 256u;
+  uint64_t nb = (uint64_t)a.blocks_per_image * (uint64_t)B;
+  if (nb > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
+  a.n_blocks = (unsigned)nb;
+  dim3 grid(a.n_blocks), block(256);
+#define LAUNCH_BWD(V, M) hipLaunchKernelGGL((layer_bwd_kernel<V, M>), grid, block, 0, s, a)
+  if (aligned) {
+    if (mask_kind == CURL_MASK_U8) LAUNCH_BWD(4, CURL_MASK_U8);
+    else if (mask_kind == CURL_MASK_F32) LAUNCH_BWD(4, CURL_MASK_F32);
+    else LAUNCH_BWD(4, CURL_MASK_NONE);
+  } else {
+    if (mask_kind == CURL_MASK_U8) LAUNCH_BWD(1, CURL_MASK_U8);
+    else if (mask_kind == CURL_MASK_F32) LAUNCH_BWD(1, CURL_MASK_F32);
+    else LAUNCH_BWD(1, CURL_MASK_NONE);
+  }
+#undef LAUNCH_BWD
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "layer_bwd_kernel");
+  KnotsBwdArgs kb;
+  kb.ws = ws;
+  kb.partial = (const float*)scratch;
+  kb.greg = grad_reg;
+  kb.graw[0] = grad_rawL;
+  kb.graw[1] = grad_rawR;
+  kb.graw[2] = grad_rawH;
+  kb.K[0] = Kl;
+  kb.K[1] = Kr;
+  kb.K[2] = Kh;
+  kb.ws_stride = stride;
+  kb.blocks_per_image = a.blocks_per_image;
+  hipLaunchKernelGGL(knots_bwd_kernel, dim3(B), dim3(256), 0, s, kb);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "knots_bwd_kernel");
+  return 0;
 }
 
 int curl_u8hwc_to_f32chw(const uint8_t* in, float* out, int B, int H, int W, int Cin, curl_stream_t stream) {

@@ -16,18 +16,15 @@ class _CurlLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, mask, L, R, H):
         out, reg = ops.curl_layer_forward(img, mask, L, R, H)
-        ctx.save_for_backward(img, L, R, H)
+        ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous())
         ctx.mask = mask
         return out, reg
 
     @staticmethod
     def backward(ctx, grad_out, grad_reg):
         img, L, R, H = ctx.saved_tensors
-        if not hasattr(ops, "curl_layer_backward"):
-            raise NotImplementedError(
-                "curl_amd: the fused backward kernel is not built yet; run the layer under torch.no_grad()")
         need_img = ctx.needs_input_grad[0]
-        g_img, gL, gR, gH = ops.curl_layer_backward(img, ctx.mask, L, R, H, grad_out, grad_reg, need_img)
+        g_img, gL, gR, gH = ops.curl_layer_backward(img, ctx.mask, L, R, H, grad_out.contiguous(), grad_reg, need_img)
         return g_img, None, gL, gR, gH
 
 

@@ -195,6 +195,37 @@ def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     return out, reg
 
 
+def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True):
+    """Backward of curl_layer_forward (what autograd would run through model.py:137-176).
+    -> (grad_img or None, grad_L, grad_R, grad_H)."""
+    lib = _lib.load()
+    img = _image(img)
+    grad_out = _image(grad_out, "grad_out")
+    if grad_out.shape != img.shape:
+        raise ValueError(f"grad_out {tuple(grad_out.shape)} does not match img {tuple(img.shape)}")
+    B, _, Hh, W = img.shape
+    Lc, Kl = _knots(L, "L", 3, B)
+    Rc, Kr = _knots(R, "R", 3, B)
+    Hc, Kh = _knots(H, "H", 4, B)
+    m, kind = _mask(mask, img)
+    if grad_reg is not None:
+        _need_device(grad_reg, "grad_reg")
+        grad_reg = grad_reg.to(torch.float32).contiguous()
+        if grad_reg.shape != (B,):
+            raise ValueError("grad_reg must be [B]")
+    g_img = torch.empty_like(img) if need_grad_img else None
+    gL, gR, gH = torch.empty_like(Lc), torch.empty_like(Rc), torch.empty_like(Hc)
+    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
+    sbytes = lib.curl_layer_bwd_scratch_bytes(B, Hh, W)
+    scratch = torch.empty(sbytes // 4, dtype=torch.float32, device=img.device)
+    rc = lib.curl_layer_bwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
+                                grad_out.data_ptr(), _ptr(grad_reg), _ptr(g_img), gL.data_ptr(), gR.data_ptr(),
+                                gH.data_ptr(), ws.data_ptr(), nbytes, scratch.data_ptr(), sbytes, B, Hh, W, Kl, Kr, Kh,
+                                0, _stream(img))
+    _lib.check(rc, "curl_layer_bwd_f32")
+    return g_img, gL, gR, gH
+
+
 # ------------------------------------------------------------------ layout edges
 def u8hwc_to_f32chw(x):
     """uint8 [B,H,W,3|4] (or [H,W,C]) -> float32 [B,3,H,W] = value/255 (infer.py:35-40, transpose.py:19-31)."""

@@ -122,6 +122,22 @@ int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind,
                        int B, int H, int W, int Kl, int Kr, int Kh,
                        unsigned flags, curl_stream_t stream);
 
+/* replaces: torch autograd through CURLLayer.forward (model.py:137-176 over curves.py / colors.py), i.e. what
+ *           loss.backward() runs for this layer in main.py:287.  One pass over the pixels (forward chain
+ *           recomputed in registers) + a per-image pass for the knots.
+ * grad_out [B,3,H,W]; grad_reg [B] (nullable = zeros): gradients of the two outputs of curl_layer_fwd_f32.
+ * Outputs: grad_img [B,3,H,W] (nullable: skipped), grad_rawL/R/H shaped like rawL/R/H (ASSIGNED, required).
+ * workspace: curl_workspace_bytes(B, 3*Kl+3*Kr+4*Kh); scratch: curl_layer_bwd_scratch_bytes(B,H,W) bytes
+ * (block partial sums; reduced in a fixed order in float64 -- no float atomics, results are reproducible). */
+size_t curl_layer_bwd_scratch_bytes(int B, int H, int W);
+int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind,
+                       const float* rawL, const float* rawR, const float* rawH,
+                       const float* grad_out, const float* grad_reg,
+                       float* grad_img, float* grad_rawL, float* grad_rawR, float* grad_rawH,
+                       void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                       int B, int H, int W, int Kl, int Kr, int Kh,
+                       unsigned flags, curl_stream_t stream);
+
 /* replaces: PIL + TF.to_tensor + transpose.swapimdims_HW3_3HW at the file edge
  *           infer.py:35-40, data.py:133-158, transpose.py:19-31
  * in: uint8 [B,H,W,Cin] with Cin = 3 or 4 (alpha dropped); out: float32 [B,3,H,W] = value/255. */

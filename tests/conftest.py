@@ -50,10 +50,11 @@ def twin():
     """Test-only host build of curl_amd/csrc/curl_math.h (tests/twin/curl_twin.cpp)."""
     src = os.path.join(ROOT, "tests", "twin", "curl_twin.cpp")
     hdr = os.path.join(ROOT, "curl_amd", "csrc", "curl_math.h")
+    hdr2 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_bwd.h")
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libcurl_twin.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
         subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
                                "-DCURL_HOST_TWIN", "-Wno-unknown-pragmas", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -103,6 +104,16 @@ def twin():
             lib.twin_layer(stage, P(img), P(mask), P(L), P(R), P(H), P(out), P(reg), B, ctypes.c_long(Hh * W),
                            L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4, int(binary))
             return out, reg
+
+        @staticmethod
+        def layer_bwd(img, mask, L, R, H, gout, greg):
+            img, mask, L, R, H, gout, greg = (f32(a) for a in (img, mask, L, R, H, gout, greg))
+            B, _, Hh, W = img.shape
+            gimg = np.empty_like(img)
+            gL, gR, gH = np.empty_like(L), np.empty_like(R), np.empty_like(H)
+            lib.twin_layer_bwd(P(img), P(mask), P(L), P(R), P(H), P(gout), P(greg), P(gimg), P(gL), P(gR), P(gH), B,
+                               ctypes.c_long(Hh * W), L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4)
+            return gimg, gL, gR, gH
 
     return Twin
 

@@ -1,0 +1,82 @@
+"""Backward arithmetic (curl_amd/csrc/curl_math_bwd.h) on the host twin against (1) the golden gradients
+produced by autograd THROUGH THE REFERENCE's primitives and (2) autograd through the oracle on random data,
+incl. tie / clamp / mask corner cases."""
+import numpy as np
+import pytest
+import torch
+
+import curl_oracle as O
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def oracle_grads(img, mask, L, R, H, w, wr):
+    x = img.clone().requires_grad_(True)
+    Lg, Rg, Hg = (t.clone().requires_grad_(True) for t in (L, R, H))
+    out, reg = O.curl_layer(x, mask, Lg, Rg, Hg)
+    ((out * w).sum() + (reg * wr).sum()).backward()
+    return x.grad, Lg.grad, Rg.grad, Hg.grad
+
+
+@pytest.mark.parametrize("sig", ["s01", "s05"])
+def test_golden_gradients(twin, golden, sig):
+    c = golden("chain")
+    gi, gL, gR, gH = twin.layer_bwd(c["img"], c["mask_disk"].astype(np.float32), c[sig + "_L"], c[sig + "_R"],
+                                    c[sig + "_H"], c[sig + "_grad_w"], c[sig + "_grad_wr"])
+    tol = 2e-4 if sig == "s01" else 5e-3  # strong curves: the reference's own fp32 gradient noise grows
+    assert rel(gL, c[sig + "_grad_L"]) <= tol
+    assert rel(gR, c[sig + "_grad_R"]) <= tol
+    assert rel(gH, c[sig + "_grad_H"]) <= tol
+    d = np.abs(gi - c[sig + "_grad_img"])
+    scale = np.abs(c[sig + "_grad_img"]).max()
+    assert np.quantile(d, 0.999) <= tol * scale and d.max() <= 20 * tol * scale
+
+
+@pytest.mark.parametrize("case", ["random", "grid8", "saturated", "softmask"])
+def test_vs_oracle_autograd(twin, case):
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    B, H, W = 2, 24, 32
+    img = torch.rand(B, 3, H, W, generator=g)
+    mask = torch.ones(B, 1, H, W)
+    if case == "grid8":
+        img = torch.randint(0, 256, (B, 3, H, W), generator=g).float() / 255  # ties on the 8-bit grid
+        img[:, 1, :4] = img[:, 0, :4]
+        img[:, 2, 4:8] = img[:, 1, 4:8]
+    if case == "saturated":
+        img = (img * 1.6 - 0.3)  # out-of-range inputs: clamps active
+    if case == "softmask":
+        mask = torch.rand(B, 1, H, W, generator=g)
+    else:
+        mask = (torch.rand(B, 1, H, W, generator=g) > 0.2).float()
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (48, 48, 64))
+    w = torch.randn(B, 3, H, W, generator=g)
+    wr = torch.rand(B, generator=g)
+    ref = oracle_grads(img, mask, L, R, Hk, w, wr)
+    got = twin.layer_bwd(img.numpy(), mask.numpy(), L.numpy(), R.numpy(), Hk.numpy(), w.numpy(), wr.numpy())
+    for name, a, b in zip(("img", "L", "R", "H"), got, ref):
+        b = b.numpy()
+        if name == "img":
+            d = np.abs(a - b)
+            scale = np.abs(b).max()
+            # isolated pixels sit on a discontinuity of the reference (tie / threshold flips under rounding)
+            assert np.quantile(d, 0.995) <= 3e-4 * scale, (case, name)
+        else:
+            assert rel(a, b) <= 1e-3, (case, name, rel(a, b))
+
+
+def test_regulariser_gradient_only(twin):
+    """gout = 0: the knot gradient is the regulariser's alone (curves.py:19,24 through exp)."""
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    img = torch.rand(B, 3, 4, 4, generator=g)
+    mask = torch.ones(B, 1, 4, 4)
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.3 for n in (48, 48, 64))
+    wr = torch.rand(B, generator=g) + 0.5
+    ref = oracle_grads(img, mask, L, R, Hk, torch.zeros(B, 3, 4, 4), wr)
+    got = twin.layer_bwd(img.numpy(), mask.numpy(), L.numpy(), R.numpy(), Hk.numpy(), np.zeros((B, 3, 4, 4)), wr.numpy())
+    for a, b in zip(got[1:], ref[1:]):
+        assert rel(a, b.numpy()) <= 2e-5
+    assert np.abs(got[0]).max() == 0

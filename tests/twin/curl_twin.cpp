@@ -9,7 +9,7 @@
 #include <cstdint>
 #include <vector>
 
-#include "../../curl_amd/csrc/curl_math.h"
+#include "../../curl_amd/csrc/curl_math_bwd.h"
 
 using namespace curlm;
 
@@ -131,6 +131,38 @@ int twin_layer(int stage, const float* img, const float* mask, const float* rawL
       float* q = out + (size_t)b * 3 * HW + i;
       q[0] = y.c0, q[HW] = y.c1, q[2 * HW] = y.c2;
     }
+  }
+  return 0;
+}
+
+// Backward of twin_layer(stage=1): d loss/d img, d loss/d raw knots, given d loss/d out and d loss/d reg.
+int twin_layer_bwd(const float* img, const float* mask, const float* rawL, const float* rawR, const float* rawH,
+                   const float* gout, const float* greg, float* gimg, float* gL, float* gR, float* gH, int B, long HW,
+                   int Kl, int Kr, int Kh) {
+  std::vector<float> kl(3 * Kl), kr(3 * Kr), kh(4 * Kh);
+  for (int b = 0; b < B; ++b) {
+    LayerCoef k;
+    float r;
+    prep(rawL + (size_t)b * 3 * Kl, 3, Kl, k.lab, kl.data(), r);
+    prep(rawR + (size_t)b * 3 * Kr, 3, Kr, k.rgb, kr.data(), r);
+    prep(rawH + (size_t)b * 4 * Kh, 4, Kh, k.hsv, kh.data(), r);
+    double P[10] = {0}, Q[10] = {0};
+    for (long i = 0; i < HW; ++i) {
+      const float* p = img + (size_t)b * 3 * HW + i;
+      const float* g = gout + (size_t)b * 3 * HW + i;
+      float m = mask ? mask[(size_t)b * HW + i] : 1.0f;
+      float Pf[10] = {0}, Qf[10] = {0};
+      Px gi = curl_layer_bwd(Px{p[0], p[HW], p[2 * HW]}, m, k, Px{g[0], g[HW], g[2 * HW]}, Pf, Qf);
+      for (int c = 0; c < 10; ++c) P[c] += Pf[c], Q[c] += Qf[c];
+      if (gimg) {
+        float* q = gimg + (size_t)b * 3 * HW + i;
+        q[0] = gi.c0, q[HW] = gi.c1, q[2 * HW] = gi.c2;
+      }
+    }
+    double gr = greg ? (double)greg[b] : 0.0;
+    for (int c = 0; c < 3; ++c) knots_bwd(kl.data() + c * Kl, Kl, P[c], Q[c], gr, gL + (size_t)b * 3 * Kl + c * Kl);
+    for (int c = 0; c < 3; ++c) knots_bwd(kr.data() + c * Kr, Kr, P[3 + c], Q[3 + c], gr, gR + (size_t)b * 3 * Kr + c * Kr);
+    for (int c = 0; c < 4; ++c) knots_bwd(kh.data() + c * Kh, Kh, P[6 + c], Q[6 + c], gr, gH + (size_t)b * 4 * Kh + c * Kh);
   }
   return 0;
 }
