@@ -62,8 +62,8 @@ def test_autograd_matches_oracle(dev, shape):
     wr = torch.rand(B, generator=g)
 
     def run(layer_fn, device, mask_t):
-        x = img.to(device).requires_grad_(True)
-        k = knots.to(device).requires_grad_(True)
+        x = img.detach().clone().to(device).requires_grad_(True)
+        k = knots.detach().clone().to(device).requires_grad_(True)
         L, R, Hk = k[:, :48], k[:, 50:98], k[:, 100:164]
         out, reg = layer_fn(x, mask_t.to(device), L, R, Hk)
         ((out * w.to(device)).sum() + (reg * wr.to(device)).sum()).backward()
