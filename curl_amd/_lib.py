@@ -48,6 +48,7 @@ SIGNATURES = {
                                 _c_f, _sz, _c_f, _sz, _i, _i, _i, _i, _i, _i, _u, _c_f]),
     "curl_u8hwc_to_f32chw": (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f]),
     "curl_f32chw_to_u8hwc": (_i, [_c_f, _c_f, _i, _i, _i, _c_f]),
+    "curl_compose_white_u8hwc": (_i, [_c_f, _c_f, _i, _c_f, _i, _i, _i, _c_f]),
 }
 
 _lib = None

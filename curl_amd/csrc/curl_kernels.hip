@@ -662,6 +662,25 @@ __global__ __launch_bounds__(256) void f32chw_to_u8hwc_kernel(const float* in, u
   }
 }
 
+// infer.py:46-47: out*mask + (1-mask) (white background where the mask is 0), then to_pil_image's
+// mul(255).byte() -- fused into the egress.  mask: u8 (MK 1) or f32 (MK 2), [B,1,H,W].
+__global__ __launch_bounds__(256) void compose_white_u8hwc_kernel(const float* in, const void* mask, int mask_kind,
+                                                                  uint8_t* out, size_t HW, size_t total) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  size_t b = i / HW, p = i - b * HW;
+  const float* s = in + b * 3 * HW + p;
+  float m = (mask_kind == CURL_MASK_U8) ? (reinterpret_cast<const uint8_t*>(mask)[i] ? 1.0f : 0.0f)
+                                        : reinterpret_cast<const float*>(mask)[i];
+  uint8_t* d = out + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = (s[c * HW] * m + (1.0f - m)) * 255.0f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    d[c] = (uint8_t)(int)v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1079,6 +1098,21 @@ int curl_f32chw_to_u8hwc(const float* in, uint8_t* out, int B, int H, int W, cur
                      in, out, HW, total);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "f32chw_to_u8hwc");
+  return 0;
+}
+
+int curl_compose_white_u8hwc(const float* in, const void* mask, int mask_kind, uint8_t* out, int B, int H, int W,
+                             curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(in, out, B, H, W)) return rc;
+  if (mask_kind != CURL_MASK_U8 && mask_kind != CURL_MASK_F32) return fail(CURL_E_MASK, "mask_kind must be 1 (u8) or 2 (f32)");
+  if (!mask) return fail(CURL_E_MASK, "mask is NULL");
+  size_t HW = (size_t)H * W, total = HW * (size_t)B;
+  if ((total + 255) / 256 > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
+  hipLaunchKernelGGL(compose_white_u8hwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, mask, mask_kind, out, HW, total);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "compose_white_u8hwc");
   return 0;
 }
 

@@ -256,3 +256,21 @@ def f32chw_to_u8hwc(x):
     out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=x.device)
     _lib.check(lib.curl_f32chw_to_u8hwc(x.data_ptr(), out.data_ptr(), B, H, W, _stream(x)), "curl_f32chw_to_u8hwc")
     return out[0] if squeeze else out
+
+
+def compose_white_u8hwc(x, mask):
+    """infer.py:46-47 in one pass: x*mask + (1-mask), then (.*255) truncated to uint8, CHW -> HWC."""
+    lib = _lib.load()
+    squeeze = isinstance(x, torch.Tensor) and x.dim() == 3
+    if squeeze:
+        x = x.unsqueeze(0)
+        mask = mask.unsqueeze(0) if mask.dim() == 3 else mask
+    x = _image(x, "x")
+    m, kind = _mask(mask, x)
+    if m is None:
+        raise ValueError("compose_white_u8hwc needs a mask")
+    B, _, H, W = x.shape
+    out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.curl_compose_white_u8hwc(x.data_ptr(), m.data_ptr(), kind, out.data_ptr(), B, H, W, _stream(x)),
+               "curl_compose_white_u8hwc")
+    return out[0] if squeeze else out

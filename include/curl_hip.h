@@ -146,6 +146,12 @@ int curl_u8hwc_to_f32chw(const uint8_t* in, float* out, int B, int H, int W, int
  * TRUNCATING conversion (values are expected in [0,1]; outside, they saturate to 0/255). */
 int curl_f32chw_to_u8hwc(const float* in, uint8_t* out, int B, int H, int W, curl_stream_t stream);
 
+/* replaces: `out_img * tmask + (1 - tmask)` + TF.to_pil_image (mul(255).byte())   infer.py:46-47
+ * White background where the mask is 0, then the truncating u8 HWC egress, in one pass.
+ * mask [B,1,H,W], mask_kind CURL_MASK_U8 or CURL_MASK_F32. */
+int curl_compose_white_u8hwc(const float* in, const void* mask, int mask_kind, uint8_t* out,
+                             int B, int H, int W, curl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,3 +404,36 @@ def test_gcurlnet_forward(dev):
     ref, rreg = O.curl_layer(img.cpu(), mask.cpu().float(), L, R, H)
     assert max_err(N(out), ref.numpy()) <= 2e-5
     np.testing.assert_allclose(N(reg), rreg.numpy(), rtol=1e-5)
+
+
+def test_compose_white_background(ops, dev):
+    """infer.py:46-47 fused: x*mask + (1-mask), *255, truncate, CHW->HWC."""
+    import curl_oracle as O
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 9, 13, generator=g)
+    for mask in (torch.rand(2, 1, 9, 13, generator=g) > 0.4, torch.rand(2, 1, 9, 13, generator=g)):
+        want = np.stack([O.f32chw_to_u8hwc(O.white_background(x[b], mask[b].float())) for b in range(2)])
+        got = ops.compose_white_u8hwc(x.to(dev), mask.to(dev))
+        assert (N(got).astype(int) - want.astype(int)).__abs__().max() <= 1  # fma vs mul+add at a truncation edge
+        assert (N(got) != want).mean() < 0.01
+
+
+def test_infer_cli_end_to_end(dev, tmp_path):
+    """The reference's CLI flags (infer.py:14-17) on a synthetic RGBA file + mask: runs, writes a PNG whose
+    background is white where the mask is 0 and whose foreground equals the layer applied at full resolution."""
+    from PIL import Image
+    from curl_amd import infer as cli
+    g = np.random.default_rng(0)
+    H, W = 200, 333  # not multiples of anything
+    rgba = g.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    mask[40:160, 60:300] = 255
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "in.png")
+    Image.fromarray(mask, "L").save(tmp_path / "mask.png")
+    torch.manual_seed(0)
+    cli.infer(["--img_path", str(tmp_path / "in.png"), "--mask_path", str(tmp_path / "mask.png"),
+               "--model_file", "random", "--out_path", str(tmp_path / "out.png")])
+    out = np.asarray(Image.open(tmp_path / "out.png"))
+    assert out.shape == (H, W, 3) and out.dtype == np.uint8
+    assert (out[mask == 0] == 255).all()
+    assert out[mask == 255].std() > 0

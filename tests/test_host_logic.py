@@ -120,3 +120,35 @@ def test_image_shard_is_a_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard.image_shard(4, 2, 2)
+
+
+def test_convert_state_dict_matches_reference(reference_modules):
+    import importlib
+    import sys
+    from conftest import REFERENCE
+    from curl_amd.convert_state import convert_state_dict
+    sys.path.insert(0, REFERENCE)
+    try:
+        ref = importlib.import_module("convert_state")
+    finally:
+        sys.path.remove(REFERENCE)
+    g = torch.Generator().manual_seed(0)
+    sd = {"module.rgb2lab.rgb_to_xyz": torch.rand(3, 3, generator=g), "module.lab2rgb.lab_to_fxfyfz": torch.rand(3, 3, generator=g),
+          "lab2rgb.xyz_to_rgb": torch.rand(1, 1, 3, 3, generator=g), "module.backbone.classifier.weight": torch.rand(4, 5, generator=g),
+          "rgb2hsv.comparison_zero": torch.tensor(0.0)}
+    a, b = convert_state_dict(sd), ref.convert_state_dict(sd)
+    assert list(a) == list(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_reference_style_checkpoint_loads_into_curllayer():
+    """A DDP-saved state dict with old 2-D colour matrices loads into the mirror layer key for key."""
+    from curl_amd.convert_state import convert_state_dict
+    layer = model.CURLLayer()
+    old_2d = ("rgb2lab.rgb_to_xyz", "rgb2lab.fxfyfz_to_lab", "lab2rgb.xyz_to_rgb", "lab2rgb.lab_to_fxfyfz")
+    sd = {"module." + k: (v[0, 0].t().clone() if k in old_2d else v.clone()) for k, v in layer.state_dict().items()}
+    layer2 = model.CURLLayer()
+    layer2.load_state_dict(convert_state_dict(sd))
+    for k, v in layer.state_dict().items():
+        assert torch.equal(v, layer2.state_dict()[k])
