@@ -17,7 +17,6 @@ F_PWL = 0x2
 F_TUNE_UNROLL_SHIFT = 8
 F_TUNE_NT_LOAD = 0x1000
 F_TUNE_NT_STORE = 0x2000
-F_TUNE_XCD_REMAP = 0x4000
 F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
 MAX_KNOTS = 256

@@ -132,7 +132,7 @@ struct StreamArgs {
   unsigned n;                 // elements per plane in units of VEC floats
   unsigned blocks_per_image;  // chunks per image
   unsigned n_blocks;          // total
-  int nt_load, nt_store, xcd_remap;
+  int nt_load, nt_store;
   int no_mem;  // diagnostics: synthesise inputs, suppress stores (VALU-only timing; results undefined)
 };
 
@@ -166,17 +166,6 @@ __device__ __forceinline__ void set_lane(v4f& v, int e, float x) { v[e] = x; }
 __device__ __forceinline__ void set_lane(float& v, int, float x) { v = x; }
 __device__ __forceinline__ float mlane(const v4b& v, int e) { return v[e] ? 1.0f : 0.0f; }
 __device__ __forceinline__ float mlane(const unsigned char& v, int) { return v ? 1.0f : 0.0f; }
-
-// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  With the remap each XCD walks
-// one contiguous eighth of the batch, so its L2/fabric sees sequential DRAM pages.  Bijective for any
-// n_blocks: ids in the ragged tail keep their place.
-__device__ __forceinline__ unsigned remap_block(unsigned bid, unsigned n_blocks, int on) {
-  if (!on) return bid;
-  unsigned per = n_blocks >> 3;
-  unsigned body = per << 3;
-  if (bid >= body) return bid;
-  return (bid & 7u) * per + (bid >> 3);
-}
 
 // Op contract:  struct Op { struct K {...}; static K load(const float* ws_image);  // uniform
 //                           static Px apply(Px in, float m, const K&); static constexpr bool kMask; }
@@ -240,16 +229,25 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
       live = __builtin_amdgcn_ballot_w64(lane_live) != 0ull;
     }
     if (live) {
+      PxN<VEC> px;
+      float mm[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float m = 1.0f;
-        if (MK == CURL_MASK_U8) m = mlane(t.mb[u], e);
-        if (MK == CURL_MASK_F32) m = lane(t.mf[u], e);
-        Px o = Op::template apply<kBinary>(Px{lane(t.x0[u], e), lane(t.x1[u], e), lane(t.x2[u], e)}, m, k);
+        px.c0[e] = lane(t.x0[u], e);
+        px.c1[e] = lane(t.x1[u], e);
+        px.c2[e] = lane(t.x2[u], e);
+        mm[e] = 1.0f;
+        if (MK == CURL_MASK_U8) mm[e] = mlane(t.mb[u], e);
+        if (MK == CURL_MASK_F32) mm[e] = lane(t.mf[u], e);
+      }
+      Op::template apply_n<kBinary, VEC>(px, mm, k);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        Px o{px.c0[e], px.c1[e], px.c2[e]};
         if (Op::kBlendMaskedOut && MK == CURL_MASK_U8) {
           // the binary specialisation leaves m == 0 pixels to us: overwrite with the masked-out constant
           Px z = Op::masked_out(k);
-          int keep = opaque(-(int)(m != 0.0f));
+          int keep = opaque(-(int)(mm[e] != 0.0f));
           o.c0 = blend(keep, o.c0, z.c0);
           o.c1 = blend(keep, o.c1, z.c1);
           o.c2 = blend(keep, o.c2, z.c2);
@@ -285,9 +283,10 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
 template <class Op, int VEC, int U, int MK>
 __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
   typedef typename Pack<VEC>::T T;
-  const unsigned bid = remap_block(blockIdx.x, a.n_blocks, a.xcd_remap);
-  const unsigned img = bid / a.blocks_per_image;
-  const unsigned chunk = bid - img * a.blocks_per_image;
+  // grid = (chunks per image, images): both indices are SGPRs, no division
+  const unsigned img = blockIdx.y;
+  const unsigned chunk = blockIdx.x;
+  __builtin_assume(a.n <= (1u << 28));  // H*W <= 2^30 (checked on the host): byte offsets fit 32 bits
   const typename Op::K k = Op::load(a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr);
   const size_t plane = (size_t)a.n;
   const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
@@ -309,15 +308,15 @@ struct NoK {};
     static constexpr bool kMask = false;                                                 \
     static constexpr int kUnroll = 2;                                                    \
     static __device__ __forceinline__ K load(const float*) { return K{}; }               \
-    template <bool>                                                                      \
-    static __device__ __forceinline__ Px apply(Px p, float, const K&) { return FN(p); }  \
+    template <bool, int N>                                                               \
+    static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K&) { FN(p); } \
     static constexpr bool kBlendMaskedOut = false;                                       \
     static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; } \
   };
-CONVERTER_OP(OpRgb2Lab, rgb2lab)
-CONVERTER_OP(OpLab2Rgb, lab2rgb)
-CONVERTER_OP(OpRgb2Hsv, rgb2hsv)
-CONVERTER_OP(OpHsv2Rgb, hsv2rgb)
+CONVERTER_OP(OpRgb2Lab, rgb2lab_n<N>)
+CONVERTER_OP(OpLab2Rgb, lab2rgb_n<N>)
+CONVERTER_OP(OpRgb2Hsv, rgb2hsv_n<N>)
+CONVERTER_OP(OpHsv2Rgb, hsv2rgb_n<N>)
 
 __device__ __forceinline__ Affine load_affine(const float* ws, int c) {
   return Affine{ws[WS_COEF + 2 * c], ws[WS_COEF + 2 * c + 1]};
@@ -335,8 +334,14 @@ struct OpAdjust3 {  // adjust_rgb / adjust_lab, affine form
     for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
     return k;
   }
-  template <bool>
-  static __device__ __forceinline__ Px apply(Px p, float, const K& k) { return adjust3(p, k.k[0], k.k[1], k.k[2]); }
+  template <bool, int N>
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k.k[0], k.k[1], k.k[2]);
+      p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
+    }
+  }
   static constexpr bool kBlendMaskedOut = false;
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
@@ -352,9 +357,13 @@ struct OpAdjustHsv {
     for (int c = 0; c < 4; ++c) k.k[c] = load_affine(ws, c);
     return k;
   }
-  template <bool>
-  static __device__ __forceinline__ Px apply(Px p, float, const K& k) {
-    return adjust_hsv4(p, k.k[0], k.k[1], k.k[2], k.k[3]);
+  template <bool, int N>
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      Px o = adjust_hsv4(Px{p.c0[i], p.c1[i], p.c2[i]}, k.k[0], k.k[1], k.k[2], k.k[3]);
+      p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
+    }
   }
   static constexpr bool kBlendMaskedOut = false;
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
@@ -373,8 +382,10 @@ struct OpLabStage {
     k.masked = Px{ws[WS_MASKED], ws[WS_MASKED + 1], ws[WS_MASKED + 2]};
     return k;
   }
-  template <bool BINARY>
-  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return lab_stage<BINARY>(p, m, k.k); }
+  template <bool BINARY, int N>
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&m)[N], const K& k) {
+    lab_stage_n<BINARY, N>(p, m, k.k);
+  }
   static constexpr bool kBlendMaskedOut = true;  // lab_stage<true> computes m == 0 pixels as if m == 1
   static __device__ __forceinline__ Px masked_out(const K& k) { return k.masked; }
 };
@@ -392,8 +403,10 @@ struct OpLayer {
     for (int c = 0; c < 4; ++c) k.hsv[c] = load_affine(ws, 6 + c);
     return k;
   }
-  template <bool BINARY>
-  static __device__ __forceinline__ Px apply(Px p, float m, const K& k) { return curl_layer<BINARY>(p, m, k); }
+  template <bool BINARY, int N>
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&m)[N], const K& k) {
+    curl_layer_n<BINARY, N>(p, m, k);
+  }
   static constexpr bool kBlendMaskedOut = false;  // curl_layer ends in `* m` for every mask kind
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
@@ -422,9 +435,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   __shared__ float sC[CHAIN_MAX][CURL_MAX_KNOTS];
   __shared__ float sS[CHAIN_MAX][CURL_MAX_KNOTS];
   __shared__ float sAB[CHAIN_MAX][2];
-  const unsigned bid = blockIdx.x;
-  const unsigned img = bid / a.blocks_per_image;
-  const unsigned chunk = bid - img * a.blocks_per_image;
+  const unsigned img = blockIdx.y;
+  const unsigned chunk = blockIdx.x;
   const int K = a.K;
   // stage this image's knots and slopes in LDS
   for (int i = threadIdx.x; i < a.n_steps * K; i += 256) {
@@ -523,9 +535,9 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(BwdArgs a) {
   typedef typename Pack<VEC>::T T;
   typedef typename Pack<VEC>::M M;
   __shared__ float sPart[4][BWD_NACC];
-  const unsigned bid = blockIdx.x;
-  const unsigned img = bid / a.blocks_per_image;
-  const unsigned chunk = bid - img * a.blocks_per_image;
+  const unsigned img = blockIdx.y;
+  const unsigned chunk = blockIdx.x;
+  const unsigned bid = img * a.blocks_per_image + chunk;
   const LayerCoef k = OpLayer::load(a.coef + (size_t)img * a.coef_stride);
   const size_t plane = (size_t)a.n;
   const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
@@ -687,12 +699,13 @@ __global__ __launch_bounds__(256) void compose_white_u8hwc_kernel(const float* i
 static int check_img(const void* in, const void* out, int B, int H, int W) {
   if (!in || !out) return fail(CURL_E_NULL, "image pointer is NULL");
   if (B <= 0 || H <= 0 || W <= 0) return fail(CURL_E_SHAPE, "B, H, W must be positive");
-  if ((uint64_t)H * (uint64_t)W > 0x7fffffffull) return fail(CURL_E_SHAPE, "H*W exceeds 2^31-1");
+  if ((uint64_t)H * (uint64_t)W > (1ull << 30)) return fail(CURL_E_SHAPE, "H*W exceeds 2^30 pixels");
+  if (B > 65535) return fail(CURL_E_SHAPE, "B exceeds 65535 images per call");
   return 0;
 }
 static int check_flags(unsigned flags, unsigned allowed) {
   const unsigned tune = CURL_F_TUNE_UNROLL_MASK | CURL_F_TUNE_NT_LOAD | CURL_F_TUNE_NT_STORE |
-                        CURL_F_TUNE_XCD_REMAP | CURL_F_TUNE_NO_NT | CURL_F_DIAG_NO_MEM;
+                        CURL_F_TUNE_NO_NT | CURL_F_DIAG_NO_MEM;
   if (flags & ~(allowed | tune)) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point");
   if ((flags & CURL_F_EXACT_ORDER) && (flags & CURL_F_PWL))
     return fail(CURL_E_FLAGS, "CURL_F_EXACT_ORDER and CURL_F_PWL are exclusive");
@@ -703,8 +716,8 @@ struct Geometry {
   int vec;       // 4 or 1
   int unroll;    // 1, 2 or 4
   unsigned n;    // plane length in vec units
-  unsigned blocks_per_image, n_blocks;
-  int nt_load, nt_store, xcd;
+  unsigned blocks_per_image, n_blocks, n_images;
+  int nt_load, nt_store;
 };
 
 // Library defaults chosen from the sweep in DESIGN.md (profiles/).
@@ -731,13 +744,13 @@ static int make_geometry(Geometry& g, const void* p0, const void* p1, const void
   bool no_nt = flags & CURL_F_TUNE_NO_NT;
   g.nt_load = no_nt ? 0 : ((flags & CURL_F_TUNE_NT_LOAD) ? 1 : DEFAULT_NT_LOAD);
   g.nt_store = no_nt ? 0 : ((flags & CURL_F_TUNE_NT_STORE) ? 1 : DEFAULT_NT_STORE);
-  g.xcd = (flags & CURL_F_TUNE_XCD_REMAP) ? 1 : 0;
+  g.n_images = (unsigned)B;
   return 0;
 }
 
 template <class Op, int VEC, int MK>
 static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s) {
-  dim3 grid(g.n_blocks), block(256);
+  dim3 grid(g.blocks_per_image, g.n_images), block(256);
   switch (g.unroll) {
     case 1:
       hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK>), grid, block, 0, s, a);
@@ -773,7 +786,6 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.n_blocks = g.n_blocks;
   a.nt_load = g.nt_load;
   a.nt_store = g.nt_store;
-  a.xcd_remap = g.xcd;
   a.no_mem = (flags & CURL_F_DIAG_NO_MEM) ? 1 : 0;
   hipError_t e;
   if constexpr (Op::kMask) {
@@ -827,7 +839,7 @@ static int run_prep(const float* r0, int n0, int K0, const float* r1, int n1, in
 
 template <int VEC>
 static hipError_t launch_chain_u(const Geometry& g, const ChainArgs& a, hipStream_t s) {
-  dim3 grid(g.n_blocks), block(256);
+  dim3 grid(g.blocks_per_image, g.n_images), block(256);
   switch (g.unroll) {
     case 1:
       hipLaunchKernelGGL((chain_kernel<VEC, 1>), grid, block, 0, s, a);
@@ -1044,7 +1056,7 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind, const 
   uint64_t nb = (uint64_t)a.blocks_per_image * (uint64_t)B;
   if (nb > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
   a.n_blocks = (unsigned)nb;
-  dim3 grid(a.n_blocks), block(256);
+  dim3 grid(a.blocks_per_image, (unsigned)B), block(256);
 #define LAUNCH_BWD(V, M) hipLaunchKernelGGL((layer_bwd_kernel<V, M>), grid, block, 0, s, a)
   if (aligned) {
     if (mask_kind == CURL_MASK_U8) LAUNCH_BWD(4, CURL_MASK_U8);

@@ -117,43 +117,85 @@ struct Px {
   float c0, c1, c2;
 };
 
-// ---------------------------------------------------------------- powers
-// x^2.4 for x >= (1e-4+0.055)/1.055: x*x * 2^(0.4*log2 x).  Splitting off x^2 keeps the
-// exponent argument below 2 in magnitude, so the hardware log/exp errors (1 ulp each) cost
-// ~2e-7 relative instead of ~7e-7.
-CURL_HD float pow_gamma(float x) { return (x * x) * hw_exp2(kGammaFrac * hw_log2(x)); }
-CURL_HD float pow_inv_gamma(float x) { return hw_exp2(kInvGamma * hw_log2(x)); }
-CURL_HD float cbrt_pos(float x) { return hw_exp2(kThird * hw_log2(x)); }
+// ---------------------------------------------------------------- N pixels at a time, transcendentals clustered
+// Measured (tools/ubench/transmix.hip): a v_exp/v_log/v_rcp issued between FMA-class instructions costs
+// ~5.8 ns per SIMD, the same instruction in a run of its own kind ~4.3 ns (alone 3.5).  The converters are
+// therefore written over the N pixels a lane owns, as phases: every phase of transcendentals is a run of
+// 3N (or N) back-to-back v_log / v_exp / v_rcp, fenced so the scheduler cannot interleave it again.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CURL_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CURL_FENCE() ((void)0)
+#endif
+
+template <int N>
+struct PxN {
+  float c0[N], c1[N], c2[N];
+};
+
+// y[i] = x[i]^e for M values: M logs, M multiplies, M exps
+template <int M>
+CURL_HD void pow_run(float (&x)[M], float e) {
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] = hw_log2(x[i]);
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] *= e;
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] = hw_exp2(x[i]);
+  CURL_FENCE();
+}
 
 // ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
-CURL_HD float srgb_to_linear(float x) {
+template <int N>
+CURL_HD void rgb2lab_n(PxN<N>& p) {
+  float x[3 * N], g[3 * N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    x[3 * i] = p.c0[i];
+    x[3 * i + 1] = p.c1[i];
+    x[3 * i + 2] = p.c2[i];
+  }
   // colors.py:37-38: both branches are evaluated and blended with 0/1 masks in the reference.  The gamma
   // branch is taken only for x > 0.04045, where clamp(x, min=1e-4) is the identity, so the guard is dropped.
-  float lin = x * kInv1292;
-  float gam = pow_gamma(fmaf(x, kInv1055, (float)(0.055 / 1.055)));
-  return select_le(x, kSrgbThr, lin, gam);
-}
-CURL_HD float lab_f(float t) {
+  // u^2.4 = u*u * 2^(0.4*log2 u): splitting off u^2 keeps the exponent argument below 2 in magnitude, so the
+  // hardware log/exp errors (1 ulp each) cost ~1e-7 relative instead of ~4e-7 (the direct form fails the
+  // 1e-5 end-to-end bar on out-of-range inputs).  torch raises to float32(2.4); 2.4f - 2.0f is exact.
+  float u2[3 * N];
+#pragma unroll
+  for (int i = 0; i < 3 * N; ++i) {
+    g[i] = fmaf(x[i], kInv1055, (float)(0.055 / 1.055));
+    u2[i] = g[i] * g[i];
+  }
+  pow_run(g, kGammaFrac);
+#pragma unroll
+  for (int i = 0; i < 3 * N; ++i) x[i] = select_le(x[i], kSrgbThr, x[i] * kInv1292, u2[i] * g[i]);
+  // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white, folded into the rows)
+  float t[3 * N], f[3 * N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float r = x[3 * i], gg = x[3 * i + 1], b = x[3 * i + 2];
+    t[3 * i] = fmaf(0.180423f * kInvXn, b, fmaf(0.357580f * kInvXn, gg, (0.412453f * kInvXn) * r));
+    t[3 * i + 1] = fmaf(0.072169f, b, fmaf(0.715160f, gg, 0.212671f * r));
+    t[3 * i + 2] = fmaf(0.950227f * kInvZn, b, fmaf(0.119193f * kInvZn, gg, (0.019334f * kInvZn) * r));
+  }
   // colors.py:45-47 (cube root taken only for t > eps^3 > 1e-4)
-  float lin = fmaf(t, kInv3Eps2, k4_29);
-  float cub = cbrt_pos(t);
-  return select_le(t, kEps3, lin, cub);
-}
-CURL_HD Px rgb2lab(Px p) {
-  float r = srgb_to_linear(p.c0), g = srgb_to_linear(p.c1), b = srgb_to_linear(p.c2);
-  // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white)
-  // (the 1/white factors are folded into the matrix rows: one rounding fewer per entry, 2 multiplies saved)
-  float X = fmaf(0.180423f * kInvXn, b, fmaf(0.357580f * kInvXn, g, (0.412453f * kInvXn) * r));
-  float Y = fmaf(0.072169f, b, fmaf(0.715160f, g, 0.212671f * r));
-  float Z = fmaf(0.950227f * kInvZn, b, fmaf(0.119193f * kInvZn, g, (0.019334f * kInvZn) * r));
-  float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
+#pragma unroll
+  for (int i = 0; i < 3 * N; ++i) f[i] = t[i];
+  pow_run(f, kThird);
+#pragma unroll
+  for (int i = 0; i < 3 * N; ++i) f[i] = select_le(t[i], kEps3, fmaf(t[i], kInv3Eps2, k4_29), f[i]);
   // colors.py:18-20,50: L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz);
   // colors.py:57-59: L/100, (a/110 + 1)/2, (b/110 + 1)/2 -- constants folded.
-  Px o;
-  o.c0 = fmaf(fy, 1.16f, -0.16f);
-  o.c1 = fmaf(fx - fy, (float)(500.0 / 220.0), 0.5f);
-  o.c2 = fmaf(fy - fz, (float)(200.0 / 220.0), 0.5f);
-  return o;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+    p.c0[i] = fmaf(fy, 1.16f, -0.16f);
+    p.c1[i] = fmaf(fx - fy, (float)(500.0 / 220.0), 0.5f);
+    p.c2[i] = fmaf(fy - fz, (float)(200.0 / 220.0), 0.5f);
+  }
 }
 
 // ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
@@ -163,52 +205,94 @@ CURL_HD float lab_finv(float f) {
   float cub = f * f * f;
   return select_le(f, kEps, lin, cub);
 }
-CURL_HD float linear_to_srgb(float v) {
+template <int N>
+CURL_HD void lab2rgb_n(PxN<N>& p) {
+  float v[3 * N], g[3 * N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    // colors.py:97-99 (L*100, (a*2-1)*110, (b*2-1)*110) and colors.py:79-81,104-106
+    // (fy = (L+16)/116, fx = fy + a/500, fz = fy - b/200) with the constants folded:
+    float fy = fmaf(p.c0[i], (float)(100.0 / 116.0), (float)(16.0 / 116.0));
+    float fx = fmaf(p.c1[i], (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0));
+    float fz = fmaf(p.c2[i], (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0));
+    // colors.py:114 (x white) folded into the columns of colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
+    float X = lab_finv(fx), Y = lab_finv(fy), Z = lab_finv(fz);
+    v[3 * i] = fmaf(-0.4985314f * kZn, Z, fmaf(-1.5371385f, Y, (3.2404542f * kXn) * X));
+    v[3 * i + 1] = fmaf(0.0415560f * kZn, Z, fmaf(1.8760108f, Y, (-0.9692660f * kXn) * X));
+    v[3 * i + 2] = fmaf(1.0572252f * kZn, Z, fmaf(-0.2040259f, Y, (0.0556434f * kXn) * X));
+  }
   // colors.py:118-119 (power taken only for v > 0.0031308 > 1e-4)
-  float lin = v * 12.92f;
-  float gam = fmaf(pow_inv_gamma(v), 1.055f, -0.055f);
-  return select_le(v, kLinThr, lin, gam);
-}
-CURL_HD Px lab2rgb(Px p) {
-  // colors.py:97-99 (L*100, (a*2-1)*110, (b*2-1)*110) and colors.py:79-81,104-106
-  // (fy = (L+16)/116, fx = fy + a/500, fz = fy - b/200) with the constants folded:
-  float fy = fmaf(p.c0, (float)(100.0 / 116.0), (float)(16.0 / 116.0));
-  float fx = fmaf(p.c1, (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0));
-  float fz = fmaf(p.c2, (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0));
-  // colors.py:114 (x white) folded into the columns of colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
-  float X = lab_finv(fx), Y = lab_finv(fy), Z = lab_finv(fz);
-  float r = fmaf(-0.4985314f * kZn, Z, fmaf(-1.5371385f, Y, (3.2404542f * kXn) * X));
-  float g = fmaf(0.0415560f * kZn, Z, fmaf(1.8760108f, Y, (-0.9692660f * kXn) * X));
-  float bb = fmaf(1.0572252f * kZn, Z, fmaf(-0.2040259f, Y, (0.0556434f * kXn) * X));
-  Px o;
-  o.c0 = linear_to_srgb(r);
-  o.c1 = linear_to_srgb(g);
-  o.c2 = linear_to_srgb(bb);
-  return o;  // NOT clamped (colors.py:121-123)
+#pragma unroll
+  for (int i = 0; i < 3 * N; ++i) g[i] = v[i];
+  pow_run(g, kInvGamma);
+#pragma unroll
+  for (int i = 0; i < 3 * N; ++i) v[i] = select_le(v[i], kLinThr, v[i] * 12.92f, fmaf(g[i], 1.055f, -0.055f));
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    p.c0[i] = v[3 * i];  // NOT clamped (colors.py:121-123)
+    p.c1[i] = v[3 * i + 1];
+    p.c2[i] = v[3 * i + 2];
+  }
 }
 
 // ---------------------------------------------------------------- RGB -> HSV   colors.py:195-242
-CURL_HD Px rgb2hsv(Px p) {
-  float r = clampf(p.c0, kHsvFloor, 1.0f), g = clampf(p.c1, kHsvFloor, 1.0f), b = clampf(p.c2, kHsvFloor, 1.0f);
-  float mx = fmaxf(r, fmaxf(g, b));
-  float mn = fminf(r, fminf(g, b));
-  float df = mx - mn;
-  float dfi = rcp_refined(df);  // inf/NaN when df == 0: masked below
-  // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum.
-  // [c == mx] as a bit mask: mx - c is +0 exactly when they are equal.
-  float t0 = keep_if(zero_mask(mx - r), (g - b) * dfi);
-  float t1 = keep_if(zero_mask(mx - g), fmaf(b - r, dfi, 2.0f));
-  float t2 = keep_if(zero_mask(mx - b), fmaf(r - g, dfi, 4.0f));
-  float h = keep_if(nonzero_mask(df), (t0 + t1) + t2);  // df == 0 -> 0 (colors.py:221)
-  // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
-  h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
-  float s = df * rcp_refined(mx);       // colors.py:234-237 (mx >= 1e-9 > 0 after the clamp)
-  Px o;
-  o.c0 = clampf(h, kHsvFloor, 1.0f);    // colors.py:240
-  o.c1 = clampf(s, kHsvFloor, 1.0f);
-  o.c2 = clampf(mx, kHsvFloor, 1.0f);
-  return o;
+template <int N>
+CURL_HD void rgb2hsv_n(PxN<N>& p) {
+  float r[N], g[N], b[N], mx[N], df[N], rdm[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    r[i] = clampf(p.c0[i], kHsvFloor, 1.0f);
+    g[i] = clampf(p.c1[i], kHsvFloor, 1.0f);
+    b[i] = clampf(p.c2[i], kHsvFloor, 1.0f);
+    mx[i] = fmaxf(r[i], fmaxf(g[i], b[i]));
+    df[i] = mx[i] - fminf(r[i], fminf(g[i], b[i]));
+    // 1/df and 1/mx from ONE reciprocal: q = 1/(df*mx), 1/df = q*mx, 1/mx = q*df (df*mx >= 1e-25, no underflow).
+    // df == 0 gives inf/NaN; hue and saturation are masked to 0 below.
+    rdm[i] = df[i] * mx[i];
+  }
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < N; ++i) rdm[i] = rcp_refined(rdm[i]);
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float dfi = rdm[i] * mx[i];
+    // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum.
+    // [c == mx] as a bit mask: mx - c is +0 exactly when they are equal.
+    float t0 = keep_if(zero_mask(mx[i] - r[i]), (g[i] - b[i]) * dfi);
+    float t1 = keep_if(zero_mask(mx[i] - g[i]), fmaf(b[i] - r[i], dfi, 2.0f));
+    float t2 = keep_if(zero_mask(mx[i] - b[i]), fmaf(r[i] - g[i], dfi, 4.0f));
+    int live = nonzero_mask(df[i]);
+    float h = keep_if(live, (t0 + t1) + t2);  // df == 0 -> 0 (colors.py:221)
+    // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
+    h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
+    float s = keep_if(live, df[i] * (rdm[i] * df[i]));  // colors.py:234-237: df/mx (0 when df == 0)
+    p.c0[i] = clampf(h, kHsvFloor, 1.0f);  // colors.py:240
+    p.c1[i] = clampf(s, kHsvFloor, 1.0f);
+    p.c2[i] = clampf(mx[i], kHsvFloor, 1.0f);
+  }
 }
+
+// single-pixel forms (chain kernel, backward recompute, host twin, tests)
+CURL_HD Px rgb2lab(Px p) {
+  PxN<1> q{{p.c0}, {p.c1}, {p.c2}};
+  rgb2lab_n<1>(q);
+  return Px{q.c0[0], q.c1[0], q.c2[0]};
+}
+CURL_HD Px lab2rgb(Px p) {
+  PxN<1> q{{p.c0}, {p.c1}, {p.c2}};
+  lab2rgb_n<1>(q);
+  return Px{q.c0[0], q.c1[0], q.c2[0]};
+}
+CURL_HD Px rgb2hsv(Px p) {
+  PxN<1> q{{p.c0}, {p.c1}, {p.c2}};
+  rgb2hsv_n<1>(q);
+  return Px{q.c0[0], q.c1[0], q.c2[0]};
+}
+// powers used by the backward pass
+CURL_HD float pow_gamma(float x) { return (x * x) * hw_exp2(kGammaFrac * hw_log2(x)); }
+CURL_HD float pow_inv_gamma(float x) { return hw_exp2(kInvGamma * hw_log2(x)); }
+CURL_HD float cbrt_pos(float x) { return hw_exp2(kThird * hw_log2(x)); }
 
 // ---------------------------------------------------------------- HSV -> RGB   colors.py:131-177
 CURL_HD Px hsv2rgb(Px p) {
@@ -226,6 +310,15 @@ CURL_HD Px hsv2rgb(Px p) {
   o.c1 = clamp01(g);
   o.c2 = clamp01(b);
   return o;
+}
+
+template <int N>
+CURL_HD void hsv2rgb_n(PxN<N>& p) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Px o = hsv2rgb(Px{p.c0[i], p.c1[i], p.c2[i]});
+    p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
+  }
 }
 
 // ---------------------------------------------------------------- curves   curves.py:4-38
@@ -330,18 +423,24 @@ struct LayerCoef {
   Affine lab[3], rgb[3], hsv[4];
 };
 
+// ---------------------------------------------------------------- fused stages over the N pixels of a lane
 // model.py:151-157 : rgb2lab -> adjust_lab -> *mask -> lab2rgb
 // BINARY = the mask is known to be exactly 0 or 1 (bool / uint8 masks, or no mask at all): x*1 == x, so the
 // multiply is dropped for m == 1, and pixels with m == 0 are finished by the caller (lab_stage_masked_out).
-template <bool BINARY>
-CURL_HD Px lab_stage(Px in, float m, const Affine* k) {
-  Px lab = adjust3(rgb2lab(in), k[0], k[1], k[2]);
-  if (!BINARY) {
-    lab.c0 *= m;
-    lab.c1 *= m;
-    lab.c2 *= m;
+template <bool BINARY, int N>
+CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
+  rgb2lab_n<N>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k[0], k[1], k[2]);
+    if (!BINARY) {
+      o.c0 *= m[i];
+      o.c1 *= m[i];
+      o.c2 *= m[i];
+    }
+    p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
   }
-  return lab2rgb(lab);
+  lab2rgb_n<N>(p);
 }
 // what model.py:154-157 yields where the mask is 0: lab2rgb(0,0,0), the same colour for every such pixel
 CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }
@@ -350,27 +449,50 @@ CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }
 // (model.py:154,160,166) is the identity where m == 1, and where m == 0 the result is 0 whatever the
 // intermediates were (every stage maps finite values to finite values and model.py:170 ends in `* mask`),
 // so only the final multiply is kept.
+template <bool BINARY, int N>
+CURL_HD void curl_layer_n(PxN<N>& p, const float (&m)[N], const LayerCoef& k) {
+  PxN<N> in = p;
+  lab_stage_n<BINARY, N>(p, m, k.lab);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k.rgb[0], k.rgb[1], k.rgb[2]);  // model.py:159
+    if (!BINARY) {                                                                  // model.py:160
+      o.c0 *= m[i];
+      o.c1 *= m[i];
+      o.c2 *= m[i];
+    }
+    p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
+  }
+  rgb2hsv_n<N>(p);  // model.py:163
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Px h = adjust_hsv4(Px{p.c0[i], p.c1[i], p.c2[i]}, k.hsv[0], k.hsv[1], k.hsv[2], k.hsv[3]);  // model.py:165
+    if (!BINARY) {                                                                                 // model.py:166
+      h.c0 *= m[i];
+      h.c1 *= m[i];
+      h.c2 *= m[i];
+    }
+    Px res = hsv2rgb(h);                                   // model.py:169
+    p.c0[i] = clamp01(in.c0[i] + res.c0) * m[i];           // model.py:170
+    p.c1[i] = clamp01(in.c1[i] + res.c1) * m[i];
+    p.c2[i] = clamp01(in.c2[i] + res.c2) * m[i];
+  }
+}
+
+// single-pixel forms
+template <bool BINARY>
+CURL_HD Px lab_stage(Px in, float m, const Affine* k) {
+  PxN<1> q{{in.c0}, {in.c1}, {in.c2}};
+  const float mm[1] = {m};
+  lab_stage_n<BINARY, 1>(q, mm, k);
+  return Px{q.c0[0], q.c1[0], q.c2[0]};
+}
 template <bool BINARY>
 CURL_HD Px curl_layer(Px in, float m, const LayerCoef& k) {
-  Px rgb = lab_stage<BINARY>(in, m, k.lab);
-  rgb = adjust3(rgb, k.rgb[0], k.rgb[1], k.rgb[2]);  // model.py:159
-  if (!BINARY) {
-    rgb.c0 *= m;                                     // model.py:160
-    rgb.c1 *= m;
-    rgb.c2 *= m;
-  }
-  Px hsv = adjust_hsv4(rgb2hsv(rgb), k.hsv[0], k.hsv[1], k.hsv[2], k.hsv[3]);  // model.py:163-165
-  if (!BINARY) {
-    hsv.c0 *= m;                                     // model.py:166
-    hsv.c1 *= m;
-    hsv.c2 *= m;
-  }
-  Px res = hsv2rgb(hsv);                             // model.py:169
-  Px o;
-  o.c0 = clamp01(in.c0 + res.c0) * m;                // model.py:170
-  o.c1 = clamp01(in.c1 + res.c1) * m;
-  o.c2 = clamp01(in.c2 + res.c2) * m;
-  return o;
+  PxN<1> q{{in.c0}, {in.c1}, {in.c2}};
+  const float mm[1] = {m};
+  curl_layer_n<BINARY, 1>(q, mm, k);
+  return Px{q.c0[0], q.c1[0], q.c2[0]};
 }
 
 }  // namespace curlm

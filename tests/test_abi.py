@@ -36,7 +36,7 @@ def test_constants_match_header():
     assert int(defs["CURL_F_EXACT_ORDER"], 16) == _lib.F_EXACT_ORDER and int(defs["CURL_F_PWL"], 16) == _lib.F_PWL
     assert int(defs["CURL_MAX_KNOTS"]) == _lib.MAX_KNOTS
     assert int(defs["CURL_F_TUNE_NT_LOAD"], 16) == _lib.F_TUNE_NT_LOAD
-    assert int(defs["CURL_F_TUNE_XCD_REMAP"], 16) == _lib.F_TUNE_XCD_REMAP
+    assert int(defs["CURL_F_DIAG_NO_MEM"], 16) == _lib.F_DIAG_NO_MEM
 
 
 def test_version_and_workspace_size():
