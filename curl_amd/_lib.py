@@ -15,8 +15,6 @@ MASK_NONE, MASK_U8, MASK_F32 = 0, 1, 2
 F_EXACT_ORDER = 0x1
 F_PWL = 0x2
 F_TUNE_UNROLL_SHIFT = 8
-F_TUNE_NT_LOAD = 0x1000
-F_TUNE_NT_STORE = 0x2000
 F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
 MAX_KNOTS = 256

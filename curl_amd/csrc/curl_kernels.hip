@@ -132,7 +132,6 @@ struct StreamArgs {
   unsigned n;                 // elements per plane in units of VEC floats
   unsigned blocks_per_image;  // chunks per image
   unsigned n_blocks;          // total
-  int nt_load, nt_store;
   int no_mem;  // diagnostics: synthesise inputs, suppress stores (VALU-only timing; results undefined)
 };
 
@@ -149,16 +148,19 @@ struct Pack<1> {
   typedef unsigned char M;
 };
 
-template <typename T>
-__device__ __forceinline__ T ld(const T* p, int nt) {
-  return nt ? __builtin_nontemporal_load(p) : *p;
+// Non-temporal must be a COMPILE-TIME choice: with a run-time `nt ? __builtin_nontemporal_load(p) : *p`
+// the optimiser merges the two loads and drops the hint (no `nt` instruction was ever emitted that way).
+// Streaming data is touched once; `nt` keeps it from displacing lines in L2/MALL: +10 % on the 3-plane
+// copy pattern of this path (tools/ubench/copy3.hip: 5.56 -> 6.15 TB/s).
+template <bool NT, typename T>
+__device__ __forceinline__ T ld(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
 }
-template <typename T>
-__device__ __forceinline__ void st(T* p, T v, int nt) {
-  if (nt)
-    __builtin_nontemporal_store(v, p);
-  else
-    *p = v;
+template <bool NT, typename T>
+__device__ __forceinline__ void st(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 __device__ __forceinline__ float lane(const v4f& v, int e) { return v[e]; }
 __device__ __forceinline__ float lane(const float& v, int) { return v; }
@@ -182,7 +184,7 @@ struct Tile {
   typename Pack<VEC>::M mb[MK == CURL_MASK_U8 ? U : 1];
 };
 
-template <int VEC, int U, int MK>
+template <int VEC, int U, int MK, bool NT>
 __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs& a, const typename Pack<VEC>::T* p0,
                                           size_t plane, size_t mask_off, unsigned base) {
   typedef typename Pack<VEC>::T T;
@@ -199,15 +201,15 @@ __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs&
       if (MK == CURL_MASK_F32) t.mf[u] = T(1.0f);
       continue;
     }
-    t.x0[u] = ld(p0 + i, a.nt_load);
-    t.x1[u] = ld(p0 + plane + i, a.nt_load);
-    t.x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
-    if (MK == CURL_MASK_U8) t.mb[u] = ld(reinterpret_cast<const M*>(a.mask) + mask_off + i, a.nt_load);
-    if (MK == CURL_MASK_F32) t.mf[u] = ld(reinterpret_cast<const T*>(a.mask) + mask_off + i, a.nt_load);
+    t.x0[u] = ld<NT>(p0 + i);
+    t.x1[u] = ld<NT>(p0 + plane + i);
+    t.x2[u] = ld<NT>(p0 + 2 * plane + i);
+    if (MK == CURL_MASK_U8) t.mb[u] = ld<NT>(reinterpret_cast<const M*>(a.mask) + mask_off + i);
+    if (MK == CURL_MASK_F32) t.mf[u] = ld<NT>(reinterpret_cast<const T*>(a.mask) + mask_off + i);
   }
 }
 
-template <class Op, int VEC, int U, int MK>
+template <class Op, int VEC, int U, int MK, bool NT>
 __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const StreamArgs& a,
                                               typename Pack<VEC>::T* q0, size_t plane, unsigned base,
                                               const typename Op::K& k) {
@@ -273,14 +275,14 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
       keep = (chk == -123.0f);
     }
     if (i < a.n && keep) {
-      st(q0 + i, y0, a.nt_store);
-      st(q0 + plane + i, y1, a.nt_store);
-      st(q0 + 2 * plane + i, y2, a.nt_store);
+      st<NT>(q0 + i, y0);
+      st<NT>(q0 + plane + i, y1);
+      st<NT>(q0 + 2 * plane + i, y2);
     }
   }
 }
 
-template <class Op, int VEC, int U, int MK>
+template <class Op, int VEC, int U, int MK, bool NT>
 __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
   typedef typename Pack<VEC>::T T;
   // grid = (chunks per image, images): both indices are SGPRs, no division
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
   const size_t mask_off = (size_t)img * plane;
   const unsigned base = chunk * (256u * U) + threadIdx.x;
   Tile<VEC, U, MK> t;
-  load_tile(t, a, p0, plane, mask_off, base);
-  compute_store<Op, VEC, U, MK>(t, a, q0, plane, base, k);
+  load_tile<VEC, U, MK, NT>(t, a, p0, plane, mask_off, base);
+  compute_store<Op, VEC, U, MK, NT>(t, a, q0, plane, base, k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,7 +428,6 @@ struct ChainArgs {
   int cin[CHAIN_MAX], cout[CHAIN_MAX];
   unsigned n, blocks_per_image, n_blocks;
   int mode;  // 0 affine (collapsed in the prologue), 1 exact order, 2 PWL
-  int nt_load, nt_store;
 };
 
 template <int VEC, int U>
@@ -463,9 +464,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   for (int u = 0; u < U; ++u) {
     unsigned i = base + u * 256u;
     if (i < a.n) {
-      x0[u] = ld(p0 + i, a.nt_load);
-      x1[u] = ld(p0 + plane + i, a.nt_load);
-      x2[u] = ld(p0 + 2 * plane + i, a.nt_load);
+      x0[u] = ld<true>(p0 + i);
+      x1[u] = ld<true>(p0 + plane + i);
+      x2[u] = ld<true>(p0 + 2 * plane + i);
     }
   }
   const float S = (float)(K - 1);
@@ -497,9 +498,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
         set_lane(y1, e, c1);
         set_lane(y2, e, c2);
       }
-      st(q0 + i, y0, a.nt_store);
-      st(q0 + plane + i, y1, a.nt_store);
-      st(q0 + 2 * plane + i, y2, a.nt_store);
+      st<true>(q0 + i, y0);
+      st<true>(q0 + plane + i, y1);
+      st<true>(q0 + 2 * plane + i, y2);
     }
   }
 }
@@ -704,8 +705,7 @@ static int check_img(const void* in, const void* out, int B, int H, int W) {
   return 0;
 }
 static int check_flags(unsigned flags, unsigned allowed) {
-  const unsigned tune = CURL_F_TUNE_UNROLL_MASK | CURL_F_TUNE_NT_LOAD | CURL_F_TUNE_NT_STORE |
-                        CURL_F_TUNE_NO_NT | CURL_F_DIAG_NO_MEM;
+  const unsigned tune = CURL_F_TUNE_UNROLL_MASK | CURL_F_TUNE_NO_NT | CURL_F_DIAG_NO_MEM;
   if (flags & ~(allowed | tune)) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point");
   if ((flags & CURL_F_EXACT_ORDER) && (flags & CURL_F_PWL))
     return fail(CURL_E_FLAGS, "CURL_F_EXACT_ORDER and CURL_F_PWL are exclusive");
@@ -717,12 +717,10 @@ struct Geometry {
   int unroll;    // 1, 2 or 4
   unsigned n;    // plane length in vec units
   unsigned blocks_per_image, n_blocks, n_images;
-  int nt_load, nt_store;
+  int nt;  // non-temporal loads and stores (float4 kernels)
 };
 
 // Library defaults chosen from the sweep in DESIGN.md (profiles/).
-#define DEFAULT_NT_LOAD 0
-#define DEFAULT_NT_STORE 0
 
 static int make_geometry(Geometry& g, const void* p0, const void* p1, const void* pm, int mask_kind, int B, int H, int W,
                          unsigned flags, int default_unroll) {
@@ -741,25 +739,23 @@ static int make_geometry(Geometry& g, const void* p0, const void* p1, const void
   uint64_t nb = (uint64_t)g.blocks_per_image * (uint64_t)B;
   if (nb > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
   g.n_blocks = (unsigned)nb;
-  bool no_nt = flags & CURL_F_TUNE_NO_NT;
-  g.nt_load = no_nt ? 0 : ((flags & CURL_F_TUNE_NT_LOAD) ? 1 : DEFAULT_NT_LOAD);
-  g.nt_store = no_nt ? 0 : ((flags & CURL_F_TUNE_NT_STORE) ? 1 : DEFAULT_NT_STORE);
+  g.nt = (flags & CURL_F_TUNE_NO_NT) ? 0 : 1;
   g.n_images = (unsigned)B;
   return 0;
 }
 
-template <class Op, int VEC, int MK>
+template <class Op, int VEC, int MK, bool NT>
 static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s) {
   dim3 grid(g.blocks_per_image, g.n_images), block(256);
   switch (g.unroll) {
     case 1:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK, NT>), grid, block, 0, s, a);
       break;
     case 2:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 2, MK>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 2, MK, NT>), grid, block, 0, s, a);
       break;
     default:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 4, MK>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((stream_kernel<Op, VEC, 4, MK, NT>), grid, block, 0, s, a);
       break;
   }
   return hipGetLastError();
@@ -767,7 +763,8 @@ static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s
 
 template <class Op, int MK>
 static hipError_t launch_v(const Geometry& g, const StreamArgs& a, hipStream_t s) {
-  return (g.vec == 4) ? launch_u<Op, 4, MK>(g, a, s) : launch_u<Op, 1, MK>(g, a, s);
+  if (g.vec == 4) return g.nt ? launch_u<Op, 4, MK, true>(g, a, s) : launch_u<Op, 4, MK, false>(g, a, s);
+  return launch_u<Op, 1, MK, false>(g, a, s);  // scalar correctness path: plain accesses
 }
 
 template <class Op>
@@ -784,8 +781,6 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.n = g.n;
   a.blocks_per_image = g.blocks_per_image;
   a.n_blocks = g.n_blocks;
-  a.nt_load = g.nt_load;
-  a.nt_store = g.nt_store;
   a.no_mem = (flags & CURL_F_DIAG_NO_MEM) ? 1 : 0;
   hipError_t e;
   if constexpr (Op::kMask) {
@@ -875,8 +870,6 @@ static int launch_chain(const float* in, float* out, const float* knots, unsigne
   a.blocks_per_image = g.blocks_per_image;
   a.n_blocks = g.n_blocks;
   a.mode = mode;
-  a.nt_load = g.nt_load;
-  a.nt_store = g.nt_store;
   hipError_t e = (g.vec == 4) ? launch_chain_u<4>(g, a, s) : launch_chain_u<1>(g, a, s);
   if (e != hipSuccess) return hip_fail(e, "chain_kernel");
   return 0;

@@ -60,9 +60,7 @@ enum {
 /* tuning bits (0 = library default; used by the bench sweep, never change results) */
 #define CURL_F_TUNE_UNROLL_SHIFT 8 /* bits 8..10: float4 groups per thread, 0 = default */
 #define CURL_F_TUNE_UNROLL_MASK 0x700u
-#define CURL_F_TUNE_NT_LOAD 0x1000u  /* non-temporal loads */
-#define CURL_F_TUNE_NT_STORE 0x2000u /* non-temporal stores */
-#define CURL_F_TUNE_NO_NT 0x8000u     /* force plain loads/stores where the default is non-temporal */
+#define CURL_F_TUNE_NO_NT 0x8000u     /* plain loads/stores instead of the default non-temporal ones */
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */
 

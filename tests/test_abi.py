@@ -35,7 +35,7 @@ def test_constants_match_header():
     assert int(defs["CURL_MASK_U8"]) == _lib.MASK_U8 and int(defs["CURL_MASK_F32"]) == _lib.MASK_F32
     assert int(defs["CURL_F_EXACT_ORDER"], 16) == _lib.F_EXACT_ORDER and int(defs["CURL_F_PWL"], 16) == _lib.F_PWL
     assert int(defs["CURL_MAX_KNOTS"]) == _lib.MAX_KNOTS
-    assert int(defs["CURL_F_TUNE_NT_LOAD"], 16) == _lib.F_TUNE_NT_LOAD
+    assert int(defs["CURL_F_TUNE_NO_NT"], 16) == _lib.F_TUNE_NO_NT
     assert int(defs["CURL_F_DIAG_NO_MEM"], 16) == _lib.F_DIAG_NO_MEM
 
 

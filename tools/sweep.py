@@ -56,7 +56,7 @@ def main():
     variants = []
     for u in (1, 2, 4):
         for iters in (0,):
-            for nt in (0, _lib.F_TUNE_NT_LOAD | _lib.F_TUNE_NT_STORE, _lib.F_TUNE_NT_STORE, _lib.F_TUNE_NT_LOAD):
+            for nt in (0, _lib.F_TUNE_NO_NT):
                 for xcd in (0,):
                     variants.append((u, nt, xcd))
     names = os.environ.get("WORKLOADS", "layer_mask_u8,lab_stage_mask_u8,adjust_rgb,layer").split(",")

@@ -1,0 +1,86 @@
+// Memory-floor probe for the path's access pattern: B images x 3 planes in, 3 planes out (NCHW float32),
+// one pass.  Variants: threads per block, float4 groups per lane, one-shot tiles vs persistent grid-stride,
+// plain vs non-temporal.  Reports GB/s (read+write) sustained over 60 launches on rotating buffers.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int U, int NT>
+__global__ void k_tile(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned n /*vec per plane*/) {
+  const unsigned img = blockIdx.y;
+  const size_t plane = n;
+  const v4f* p = in + (size_t)img * 3 * plane;
+  v4f* q = out + (size_t)img * 3 * plane;
+  unsigned base = blockIdx.x * (blockDim.x * U) + threadIdx.x;
+  v4f a[U], b[U], c[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = min(base + u * blockDim.x, n - 1);
+    if (NT) { a[u] = __builtin_nontemporal_load(p + i); b[u] = __builtin_nontemporal_load(p + plane + i); c[u] = __builtin_nontemporal_load(p + 2 * plane + i); }
+    else { a[u] = p[i]; b[u] = p[plane + i]; c[u] = p[2 * plane + i]; }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * blockDim.x;
+    if (i < n) {
+      v4f x = a[u] * 1.01f, y = b[u] * 1.01f, z = c[u] * 1.01f;
+      if (NT) { __builtin_nontemporal_store(x, q + i); __builtin_nontemporal_store(y, q + plane + i); __builtin_nontemporal_store(z, q + 2 * plane + i); }
+      else { q[i] = x; q[plane + i] = y; q[2 * plane + i] = z; }
+    }
+  }
+}
+// persistent: grid = k * 256 CUs; each block strides over all (image, tile) pairs
+template <int U>
+__global__ void k_persist(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned n, unsigned tiles_per_img, unsigned total_tiles) {
+  for (unsigned t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    unsigned img = t / tiles_per_img, tile = t - img * tiles_per_img;
+    const size_t plane = n;
+    const v4f* p = in + (size_t)img * 3 * plane;
+    v4f* q = out + (size_t)img * 3 * plane;
+    unsigned base = tile * (blockDim.x * U) + threadIdx.x;
+    v4f a[U], b[U], c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { unsigned i = min(base + u * blockDim.x, n - 1); a[u] = p[i]; b[u] = p[plane + i]; c[u] = p[2 * plane + i]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { unsigned i = base + u * blockDim.x; if (i < n) { q[i] = a[u] * 1.01f; q[plane + i] = b[u] * 1.01f; q[2 * plane + i] = c[u] * 1.01f; } }
+  }
+}
+// flat copy of the whole buffer (no plane structure), for the ceiling
+template <int U>
+__global__ void k_flat(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n) {
+  size_t base = (size_t)blockIdx.x * (blockDim.x * U) + threadIdx.x;
+  v4f a[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) { size_t i = base + (size_t)u * blockDim.x; a[u] = in[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int u = 0; u < U; ++u) { size_t i = base + (size_t)u * blockDim.x; if (i < n) out[i] = a[u] * 1.01f; }
+}
+
+int main() {
+  const int B = 32, H = 1000, W = 1500;
+  const unsigned n = H * W / 4;
+  const size_t bytes = (size_t)B * 3 * n * 16;
+  v4f *in[2], *out;
+  for (auto& p : in) { hipMalloc(&p, bytes); hipMemset(p, 0x3c, bytes); }
+  hipMalloc(&out, bytes);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto bench = [&](const char* name, auto launch) {
+    for (int i = 0; i < 20; ++i) launch(in[i & 1]);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 60; ++i) launch(in[i & 1]);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 60;
+    printf("%-34s %7.1f us  %7.1f GB/s\n", name, ms * 1e3, 2.0 * bytes / ms / 1e6);
+  };
+#define TILE(T, UU, NTT) bench("tile T=" #T " U=" #UU " nt=" #NTT, [&](v4f* src) { hipLaunchKernelGGL((k_tile<UU, NTT>), dim3((n + T * UU - 1) / (T * UU), B), dim3(T), 0, 0, src, out, n); });
+  TILE(256, 1, 0) TILE(256, 2, 0) TILE(256, 4, 0) TILE(512, 1, 0) TILE(512, 2, 0) TILE(1024, 1, 0) TILE(1024, 2, 0) TILE(64, 4, 0) TILE(128, 2, 0)
+  TILE(256, 2, 1) TILE(512, 2, 1)
+#define PERS(T, UU, G) bench("persist T=" #T " U=" #UU " grid=" #G, [&](v4f* src) { unsigned tpi = (n + T * UU - 1) / (T * UU); hipLaunchKernelGGL((k_persist<UU>), dim3(G), dim3(T), 0, 0, src, out, n, tpi, tpi * B); });
+  PERS(256, 2, 2048) PERS(256, 2, 4096) PERS(256, 4, 2048) PERS(512, 2, 1024) PERS(512, 2, 2048) PERS(1024, 1, 512) PERS(1024, 2, 1024)
+#define FLAT(T, UU) bench("flat T=" #T " U=" #UU, [&](v4f* src) { size_t nn = (size_t)B * 3 * n; hipLaunchKernelGGL((k_flat<UU>), dim3((unsigned)((nn + T * UU - 1) / (T * UU))), dim3(T), 0, 0, src, out, nn); });
+  FLAT(256, 1) FLAT(256, 2) FLAT(256, 4) FLAT(512, 4) FLAT(1024, 4)
+  bench("hipMemcpyAsync D2D", [&](v4f* src) { hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, 0); });
+  return 0;
+}
