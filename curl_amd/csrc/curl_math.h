@@ -133,6 +133,84 @@ struct PxN {
   float c0[N], c1[N], c2[N];
 };
 
+// Packed FP32: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes-worth of work per instruction at
+// 1.75 ns per SIMD against 2 x 1.07 ns for the scalar forms (tools/ubench/sustained.hip).  hipcc's SLP
+// vectoriser does not form them on its own here, so the element-wise loops over a lane's pixels go through
+// these helpers: arrays are PLANE-MAJOR (index c*N + i), so elements 2k, 2k+1 are two pixels of one channel
+// and sit in adjacent registers straight from the float4 loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float curl_f2 __attribute__((ext_vector_type(2)));
+CURL_HD curl_f2 splat2(float k) {
+  curl_f2 v;
+  v.x = k;
+  v.y = k;
+  return v;
+}
+CURL_HD curl_f2 ld2(const float* a, int i) {
+  curl_f2 v;
+  v.x = a[i];
+  v.y = a[i + 1];
+  return v;
+}
+CURL_HD void st2(float* a, int i, curl_f2 v) {
+  a[i] = v.x;
+  a[i + 1] = v.y;
+}
+#endif
+
+// y = a*k + c, element-wise over M values (k, c scalars)
+template <int M>
+CURL_HD void fma_run(float (&y)[M], const float (&a)[M], float k, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i + 1 < M; i += 2) st2(y, i, __builtin_elementwise_fma(ld2(a, i), splat2(k), splat2(c)));
+  if (M & 1) y[M - 1] = fmaf(a[M - 1], k, c);
+#else
+  for (int i = 0; i < M; ++i) y[i] = fmaf(a[i], k, c);
+#endif
+}
+// y = a*b element-wise
+template <int M>
+CURL_HD void mul_run(float (&y)[M], const float (&a)[M], const float (&b)[M]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i + 1 < M; i += 2) st2(y, i, ld2(a, i) * ld2(b, i));
+  if (M & 1) y[M - 1] = a[M - 1] * b[M - 1];
+#else
+  for (int i = 0; i < M; ++i) y[i] = a[i] * b[i];
+#endif
+}
+// y = a*k
+template <int M>
+CURL_HD void scale_run(float (&y)[M], const float (&a)[M], float k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i + 1 < M; i += 2) st2(y, i, ld2(a, i) * splat2(k));
+  if (M & 1) y[M - 1] = a[M - 1] * k;
+#else
+  for (int i = 0; i < M; ++i) y[i] = a[i] * k;
+#endif
+}
+// y = k - a   (the sign of thr - x drives every threshold select)
+template <int M>
+CURL_HD void rsub_run(float (&y)[M], float k, const float (&a)[M]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i + 1 < M; i += 2) st2(y, i, splat2(k) - ld2(a, i));
+  if (M & 1) y[M - 1] = k - a[M - 1];
+#else
+  for (int i = 0; i < M; ++i) y[i] = k - a[i];
+#endif
+}
+// out = (x <= thr) ? a : b  element-wise (thr scalar)
+template <int M>
+CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, const float (&a)[M], const float (&b)[M]) {
+  float d[M];
+  rsub_run(d, thr, x);
+#pragma unroll
+  for (int i = 0; i < M; ++i) out[i] = blend(neg_mask(d[i]), b[i], a[i]);
+}
+
 // y[i] = x[i]^e for M values: M logs, M multiplies, M exps
 template <int M>
 CURL_HD void pow_run(float (&x)[M], float e) {
@@ -140,58 +218,72 @@ CURL_HD void pow_run(float (&x)[M], float e) {
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = hw_log2(x[i]);
   CURL_FENCE();
-#pragma unroll
-  for (int i = 0; i < M; ++i) x[i] *= e;
+  scale_run(x, x, e);
   CURL_FENCE();
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = hw_exp2(x[i]);
   CURL_FENCE();
 }
 
+// row r of a 3x3 matrix applied to plane-major (c*N + i) data: y[i] = m0*a[i] + m1*a[N+i] + m2*a[2N+i]
+template <int N>
+CURL_HD void mat_row(float (&y)[N], const float (&a)[3 * N], float m0, float m1, float m2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) {
+    curl_f2 acc = splat2(m0) * ld2(a, i);
+    acc = __builtin_elementwise_fma(splat2(m1), ld2(a, N + i), acc);
+    acc = __builtin_elementwise_fma(splat2(m2), ld2(a, 2 * N + i), acc);
+    st2(y, i, acc);
+  }
+  if (N & 1) y[N - 1] = fmaf(m2, a[3 * N - 1], fmaf(m1, a[2 * N - 1], m0 * a[N - 1]));
+#else
+  for (int i = 0; i < N; ++i) y[i] = fmaf(m2, a[2 * N + i], fmaf(m1, a[N + i], m0 * a[i]));
+#endif
+}
+
 // ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
 template <int N>
 CURL_HD void rgb2lab_n(PxN<N>& p) {
-  float x[3 * N], g[3 * N];
+  float x[3 * N], g[3 * N], u2[3 * N], lin[3 * N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    x[3 * i] = p.c0[i];
-    x[3 * i + 1] = p.c1[i];
-    x[3 * i + 2] = p.c2[i];
+    x[i] = p.c0[i];
+    x[N + i] = p.c1[i];
+    x[2 * N + i] = p.c2[i];
   }
   // colors.py:37-38: both branches are evaluated and blended with 0/1 masks in the reference.  The gamma
   // branch is taken only for x > 0.04045, where clamp(x, min=1e-4) is the identity, so the guard is dropped.
   // u^2.4 = u*u * 2^(0.4*log2 u): splitting off u^2 keeps the exponent argument below 2 in magnitude, so the
   // hardware log/exp errors (1 ulp each) cost ~1e-7 relative instead of ~4e-7 (the direct form fails the
   // 1e-5 end-to-end bar on out-of-range inputs).  torch raises to float32(2.4); 2.4f - 2.0f is exact.
-  float u2[3 * N];
-#pragma unroll
-  for (int i = 0; i < 3 * N; ++i) {
-    g[i] = fmaf(x[i], kInv1055, (float)(0.055 / 1.055));
-    u2[i] = g[i] * g[i];
-  }
+  fma_run(g, x, kInv1055, (float)(0.055 / 1.055));
+  mul_run(u2, g, g);
   pow_run(g, kGammaFrac);
-#pragma unroll
-  for (int i = 0; i < 3 * N; ++i) x[i] = select_le(x[i], kSrgbThr, x[i] * kInv1292, u2[i] * g[i]);
+  mul_run(g, u2, g);
+  scale_run(lin, x, kInv1292);
+  select_le_run(x, x, kSrgbThr, lin, g);
   // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white, folded into the rows)
   float t[3 * N], f[3 * N];
+  {
+    float tx[N], ty[N], tz[N];
+    mat_row<N>(tx, x, 0.412453f * kInvXn, 0.357580f * kInvXn, 0.180423f * kInvXn);
+    mat_row<N>(ty, x, 0.212671f, 0.715160f, 0.072169f);
+    mat_row<N>(tz, x, 0.019334f * kInvZn, 0.119193f * kInvZn, 0.950227f * kInvZn);
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float r = x[3 * i], gg = x[3 * i + 1], b = x[3 * i + 2];
-    t[3 * i] = fmaf(0.180423f * kInvXn, b, fmaf(0.357580f * kInvXn, gg, (0.412453f * kInvXn) * r));
-    t[3 * i + 1] = fmaf(0.072169f, b, fmaf(0.715160f, gg, 0.212671f * r));
-    t[3 * i + 2] = fmaf(0.950227f * kInvZn, b, fmaf(0.119193f * kInvZn, gg, (0.019334f * kInvZn) * r));
+    for (int i = 0; i < N; ++i) t[i] = tx[i], t[N + i] = ty[i], t[2 * N + i] = tz[i];
   }
   // colors.py:45-47 (cube root taken only for t > eps^3 > 1e-4)
 #pragma unroll
   for (int i = 0; i < 3 * N; ++i) f[i] = t[i];
   pow_run(f, kThird);
-#pragma unroll
-  for (int i = 0; i < 3 * N; ++i) f[i] = select_le(t[i], kEps3, fmaf(t[i], kInv3Eps2, k4_29), f[i]);
+  fma_run(lin, t, kInv3Eps2, k4_29);
+  select_le_run(f, t, kEps3, lin, f);
   // colors.py:18-20,50: L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz);
   // colors.py:57-59: L/100, (a/110 + 1)/2, (b/110 + 1)/2 -- constants folded.
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    float fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+    float fx = f[i], fy = f[N + i], fz = f[2 * N + i];
     p.c0[i] = fmaf(fy, 1.16f, -0.16f);
     p.c1[i] = fmaf(fx - fy, (float)(500.0 / 220.0), 0.5f);
     p.c2[i] = fmaf(fy - fz, (float)(200.0 / 220.0), 0.5f);
@@ -207,7 +299,7 @@ CURL_HD float lab_finv(float f) {
 }
 template <int N>
 CURL_HD void lab2rgb_n(PxN<N>& p) {
-  float v[3 * N], g[3 * N];
+  float X[3 * N], v[3 * N], g[3 * N], lin[3 * N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     // colors.py:97-99 (L*100, (a*2-1)*110, (b*2-1)*110) and colors.py:79-81,104-106
@@ -215,23 +307,37 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     float fy = fmaf(p.c0[i], (float)(100.0 / 116.0), (float)(16.0 / 116.0));
     float fx = fmaf(p.c1[i], (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0));
     float fz = fmaf(p.c2[i], (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0));
+    X[i] = fx, X[N + i] = fy, X[2 * N + i] = fz;
+  }
+  {
+    // colors.py:110-111 ; x**3.0 is x*x*x in torch (cube taken only for f > eps > 1e-4)
+    float cub[3 * N];
+    fma_run(lin, X, k3Eps2, -(k3Eps2 * k4_29));
+    mul_run(cub, X, X);
+    mul_run(cub, cub, X);
+    select_le_run(X, X, kEps, lin, cub);
+  }
+  {
     // colors.py:114 (x white) folded into the columns of colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
-    float X = lab_finv(fx), Y = lab_finv(fy), Z = lab_finv(fz);
-    v[3 * i] = fmaf(-0.4985314f * kZn, Z, fmaf(-1.5371385f, Y, (3.2404542f * kXn) * X));
-    v[3 * i + 1] = fmaf(0.0415560f * kZn, Z, fmaf(1.8760108f, Y, (-0.9692660f * kXn) * X));
-    v[3 * i + 2] = fmaf(1.0572252f * kZn, Z, fmaf(-0.2040259f, Y, (0.0556434f * kXn) * X));
+    float r[N], gg[N], b[N];
+    mat_row<N>(r, X, 3.2404542f * kXn, -1.5371385f, -0.4985314f * kZn);
+    mat_row<N>(gg, X, -0.9692660f * kXn, 1.8760108f, 0.0415560f * kZn);
+    mat_row<N>(b, X, 0.0556434f * kXn, -0.2040259f, 1.0572252f * kZn);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = r[i], v[N + i] = gg[i], v[2 * N + i] = b[i];
   }
   // colors.py:118-119 (power taken only for v > 0.0031308 > 1e-4)
 #pragma unroll
   for (int i = 0; i < 3 * N; ++i) g[i] = v[i];
   pow_run(g, kInvGamma);
-#pragma unroll
-  for (int i = 0; i < 3 * N; ++i) v[i] = select_le(v[i], kLinThr, v[i] * 12.92f, fmaf(g[i], 1.055f, -0.055f));
+  fma_run(g, g, 1.055f, -0.055f);
+  scale_run(lin, v, 12.92f);
+  select_le_run(v, v, kLinThr, lin, g);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    p.c0[i] = v[3 * i];  // NOT clamped (colors.py:121-123)
-    p.c1[i] = v[3 * i + 1];
-    p.c2[i] = v[3 * i + 2];
+    p.c0[i] = v[i];  // NOT clamped (colors.py:121-123)
+    p.c1[i] = v[N + i];
+    p.c2[i] = v[2 * N + i];
   }
 }
 

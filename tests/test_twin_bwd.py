@@ -37,7 +37,7 @@ def test_golden_gradients(twin, golden, sig):
 
 @pytest.mark.parametrize("case", ["random", "grid8", "saturated", "softmask"])
 def test_vs_oracle_autograd(twin, case):
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed({"random": 11, "grid8": 22, "saturated": 33, "softmask": 44}[case])
     B, H, W = 2, 24, 32
     img = torch.rand(B, 3, H, W, generator=g)
     mask = torch.ones(B, 1, H, W)

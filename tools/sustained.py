@@ -19,6 +19,7 @@ Hk = torch.randn(B, 64, device=dev) * 0.1
 ones = torch.ones(B, 1, H, W, dtype=torch.bool, device=dev)
 _lib.load()
 cnt = [0]
+FLAGS = int(os.environ.get("CURL_FLAGS", "0"), 0)
 names = sys.argv[1:] or ["rgb_only", "rgb2lab", "lab2rgb", "rgb2hsv", "lab_stage", "layer", "layer_nomem", "copy"]
 
 
@@ -26,17 +27,17 @@ def run(name):
     cnt[0] += 1
     img = imgs[cnt[0] & 1]
     if name == "layer":
-        ops.curl_layer_forward(img, ones, L, R, Hk, out=out)
+        ops.curl_layer_forward(img, ones, L, R, Hk, out=out, flags=FLAGS)
     elif name == "layer_nomem":
-        ops.curl_layer_forward(img, ones, L, R, Hk, out=out, flags=_lib.F_DIAG_NO_MEM)
+        ops.curl_layer_forward(img, ones, L, R, Hk, out=out, flags=_lib.F_DIAG_NO_MEM | FLAGS)
     elif name == "lab_stage":
-        ops.lab_stage(img, ones, L, out=out)
+        ops.lab_stage(img, ones, L, out=out, flags=FLAGS)
     elif name == "rgb_only":
-        ops.adjust_rgb(img, R)
+        ops.adjust_rgb(img, R, flags=FLAGS)
     elif name == "copy":
         out.copy_(img)
     else:
-        getattr(ops, name)(img)
+        getattr(ops, name)(img, flags=FLAGS)
 
 
 for name in names:
