@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("CURL_HIP_LIB", os.path.join(_HERE, "lib", "libcurlhip
 MASK_NONE, MASK_U8, MASK_F32 = 0, 1, 2
 F_EXACT_ORDER = 0x1
 F_PWL = 0x2
+F_RESIDUAL_ONLY = 0x4
 F_TUNE_UNROLL_SHIFT = 8
 F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
@@ -43,6 +44,8 @@ SIGNATURES = {
     "curl_layer_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "curl_layer_bwd_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_f, _sz, _c_f, _sz, _i, _i, _i, _i, _i, _i, _u, _c_f]),
+    "curl_trispace_fwd_f32": (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _u, _c_f]),
+    "curl_poly_layer_f32": (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f]),
     "curl_u8hwc_to_f32chw": (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f]),
     "curl_f32chw_to_u8hwc": (_i, [_c_f, _c_f, _i, _i, _i, _c_f]),
     "curl_compose_white_u8hwc": (_i, [_c_f, _c_f, _i, _c_f, _i, _i, _i, _c_f]),

@@ -17,6 +17,7 @@
 
 #include "../../include/curl_hip.h"
 #include "curl_math_bwd.h"
+#include "curl_math_poly.h"
 
 using namespace curlm;
 
@@ -133,6 +134,8 @@ struct StreamArgs {
   unsigned blocks_per_image;  // chunks per image
   unsigned n_blocks;          // total
   int no_mem;  // diagnostics: synthesise inputs, suppress stores (VALU-only timing; results undefined)
+  unsigned W, H;  // image size in pixels (ops that need pixel coordinates)
+  int op_flag;    // op-specific (trispace: residual only)
 };
 
 template <int VEC>
@@ -242,7 +245,7 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
         if (MK == CURL_MASK_U8) mm[e] = mlane(t.mb[u], e);
         if (MK == CURL_MASK_F32) mm[e] = lane(t.mf[u], e);
       }
-      Op::template apply_n<kBinary, VEC>(px, mm, k);
+      Op::template apply_n<kBinary, VEC>(px, mm, k, i * VEC);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         Px o{px.c0[e], px.c1[e], px.c2[e]};
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
   const unsigned img = blockIdx.y;
   const unsigned chunk = blockIdx.x;
   __builtin_assume(a.n <= (1u << 28));  // H*W <= 2^30 (checked on the host): byte offsets fit 32 bits
-  const typename Op::K k = Op::load(a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr);
+  const typename Op::K k = Op::load(a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr, a);
   const size_t plane = (size_t)a.n;
   const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
   T* q0 = reinterpret_cast<T*>(a.out) + (size_t)img * 3 * plane;
@@ -304,14 +307,17 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
 // ops
 // ------------------------------------------------------------------------------------------------
 struct NoK {};
+struct OpDefaults {
+  static constexpr bool kSingleTileShape = false;
+};
 #define CONVERTER_OP(NAME, FN)                                                           \
-  struct NAME {                                                                          \
+  struct NAME : OpDefaults {                                                             \
     typedef NoK K;                                                                       \
     static constexpr bool kMask = false;                                                 \
     static constexpr int kUnroll = 2;                                                    \
-    static __device__ __forceinline__ K load(const float*) { return K{}; }               \
+    static __device__ __forceinline__ K load(const float*, const StreamArgs&) { return K{}; } \
     template <bool, int N>                                                               \
-    static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K&) { FN(p); } \
+    static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K&, unsigned) { FN(p); } \
     static constexpr bool kBlendMaskedOut = false;                                       \
     static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; } \
   };
@@ -324,20 +330,20 @@ __device__ __forceinline__ Affine load_affine(const float* ws, int c) {
   return Affine{ws[WS_COEF + 2 * c], ws[WS_COEF + 2 * c + 1]};
 }
 
-struct OpAdjust3 {  // adjust_rgb / adjust_lab, affine form
+struct OpAdjust3 : OpDefaults {  // adjust_rgb / adjust_lab, affine form
   struct K {
     Affine k[3];
   };
   static constexpr bool kMask = false;
   static constexpr int kUnroll = 2;
-  static __device__ __forceinline__ K load(const float* ws) {
+  static __device__ __forceinline__ K load(const float* ws, const StreamArgs&) {
     K k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
     return k;
   }
   template <bool, int N>
-  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k) {
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k, unsigned) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k.k[0], k.k[1], k.k[2]);
@@ -347,20 +353,20 @@ struct OpAdjust3 {  // adjust_rgb / adjust_lab, affine form
   static constexpr bool kBlendMaskedOut = false;
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
-struct OpAdjustHsv {
+struct OpAdjustHsv : OpDefaults {
   struct K {
     Affine k[4];
   };
   static constexpr bool kMask = false;
   static constexpr int kUnroll = 2;
-  static __device__ __forceinline__ K load(const float* ws) {
+  static __device__ __forceinline__ K load(const float* ws, const StreamArgs&) {
     K k;
 #pragma unroll
     for (int c = 0; c < 4; ++c) k.k[c] = load_affine(ws, c);
     return k;
   }
   template <bool, int N>
-  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k) {
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k, unsigned) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       Px o = adjust_hsv4(Px{p.c0[i], p.c1[i], p.c2[i]}, k.k[0], k.k[1], k.k[2], k.k[3]);
@@ -370,14 +376,14 @@ struct OpAdjustHsv {
   static constexpr bool kBlendMaskedOut = false;
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
-struct OpLabStage {
+struct OpLabStage : OpDefaults {
   struct K {
     Affine k[3];
     Px masked;
   };
   static constexpr bool kMask = true;
   static constexpr int kUnroll = 1;  // arithmetic-heavy: occupancy beats per-lane ILP (profiles/sweep_r01.md)
-  static __device__ __forceinline__ K load(const float* ws) {
+  static __device__ __forceinline__ K load(const float* ws, const StreamArgs&) {
     K k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) k.k[c] = load_affine(ws, c);
@@ -385,17 +391,17 @@ struct OpLabStage {
     return k;
   }
   template <bool BINARY, int N>
-  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&m)[N], const K& k) {
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&m)[N], const K& k, unsigned) {
     lab_stage_n<BINARY, N>(p, m, k.k);
   }
   static constexpr bool kBlendMaskedOut = true;  // lab_stage<true> computes m == 0 pixels as if m == 1
   static __device__ __forceinline__ Px masked_out(const K& k) { return k.masked; }
 };
-struct OpLayer {
+struct OpLayer : OpDefaults {
   typedef LayerCoef K;
   static constexpr bool kMask = true;
   static constexpr int kUnroll = 1;
-  static __device__ __forceinline__ K load(const float* ws) {
+  static __device__ __forceinline__ K load(const float* ws, const StreamArgs&) {
     K k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) k.lab[c] = load_affine(ws, c);
@@ -406,12 +412,64 @@ struct OpLayer {
     return k;
   }
   template <bool BINARY, int N>
-  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&m)[N], const K& k) {
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&m)[N], const K& k, unsigned) {
     curl_layer_n<BINARY, N>(p, m, k);
   }
   static constexpr bool kBlendMaskedOut = false;  // curl_layer ends in `* m` for every mask kind
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
+
+// TriSpaceRegNet.generate_residual (+ generate_image), model.py:499-520: three degree-4 polynomial layers in
+// RGB / Lab / HSV + converters, one pass.  The 9 x NC coefficients of the image stay behind a uniform pointer:
+// the Horner code reads them with scalar loads straight into the SGPR operand of the packed FMAs.
+template <int V>
+struct OpTriSpace {
+  struct K {
+    const float* coef;
+    unsigned W;
+    float fW, fH;
+    bool residual_only;
+  };
+  static constexpr bool kMask = false;
+  static constexpr int kUnroll = 1;
+  static constexpr bool kSingleTileShape = true;
+  static constexpr bool kBlendMaskedOut = false;
+  static __device__ __forceinline__ K load(const float* coef_img, const StreamArgs& a) {
+    return K{coef_img, a.W, (float)a.W, (float)a.H, a.op_flag != 0};
+  }
+  template <bool, int N>
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k, unsigned pix0) {
+    float xw[N], yh[N];
+    if (V == 5) {  // cat_coords (model.py:487-497): column / width, row / height, true division
+      unsigned row = pix0 / k.W, col = pix0 - row * k.W;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        xw[i] = (float)col / k.fW;
+        yh[i] = (float)row / k.fH;
+        if (++col == k.W) col = 0, ++row;
+      }
+    }
+    trispace_n<V, N>(p, xw, yh, k.coef, k.residual_only);
+  }
+  static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
+};
+
+// ChannelPolyLayer / Deg4MobilePolyLayer forward (model.py:295-333, 399-415): img [B,V,H,W] -> [B,3,H,W].
+template <int V>
+__global__ __launch_bounds__(256) void poly_layer_kernel(const float* in, const float* coeffs, float* out, unsigned HW) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+  const unsigned img = blockIdx.y;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= HW) return;
+  const float* p = in + (size_t)img * V * HW + i;
+  float vars[V][1], o[3][1];
+#pragma unroll
+  for (int k = 0; k < V; ++k) vars[k][0] = p[(size_t)k * HW];
+  poly3_n<V, 1>(o, vars, coeffs + (size_t)img * 3 * NC);
+  float* q = out + (size_t)img * 3 * HW + i;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) q[(size_t)c * HW] = o[c][0];
+}
 
 // ------------------------------------------------------------------------------------------------
 // curve chain with the knots in LDS: reference summation order, or paper-style PWL lookup
@@ -539,7 +597,7 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(BwdArgs a) {
   const unsigned img = blockIdx.y;
   const unsigned chunk = blockIdx.x;
   const unsigned bid = img * a.blocks_per_image + chunk;
-  const LayerCoef k = OpLayer::load(a.coef + (size_t)img * a.coef_stride);
+  const LayerCoef k = OpLayer::load(a.coef + (size_t)img * a.coef_stride, StreamArgs{});
   const size_t plane = (size_t)a.n;
   const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
   const T* g0 = reinterpret_cast<const T*>(a.gout) + (size_t)img * 3 * plane;
@@ -747,16 +805,21 @@ static int make_geometry(Geometry& g, const void* p0, const void* p1, const void
 template <class Op, int VEC, int MK, bool NT>
 static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s) {
   dim3 grid(g.blocks_per_image, g.n_images), block(256);
-  switch (g.unroll) {
-    case 1:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK, NT>), grid, block, 0, s, a);
-      break;
-    case 2:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 2, MK, NT>), grid, block, 0, s, a);
-      break;
-    default:
-      hipLaunchKernelGGL((stream_kernel<Op, VEC, 4, MK, NT>), grid, block, 0, s, a);
-      break;
+  if constexpr (Op::kSingleTileShape) {
+    // very large ops (polynomial layers) are built for one tile shape only
+    hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK, NT>), grid, block, 0, s, a);
+  } else {
+    switch (g.unroll) {
+      case 1:
+        hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK, NT>), grid, block, 0, s, a);
+        break;
+      case 2:
+        hipLaunchKernelGGL((stream_kernel<Op, VEC, 2, MK, NT>), grid, block, 0, s, a);
+        break;
+      default:
+        hipLaunchKernelGGL((stream_kernel<Op, VEC, 4, MK, NT>), grid, block, 0, s, a);
+        break;
+    }
   }
   return hipGetLastError();
 }
@@ -769,8 +832,10 @@ static hipError_t launch_v(const Geometry& g, const StreamArgs& a, hipStream_t s
 
 template <class Op>
 static int launch_stream(const float* in, float* out, const void* mask, int mask_kind, const float* coef,
-                         unsigned coef_stride, int B, int H, int W, unsigned flags, hipStream_t s, const char* name) {
+                         unsigned coef_stride, int B, int H, int W, unsigned flags, hipStream_t s, const char* name,
+                         int op_flag = 0) {
   Geometry g;
+  if (Op::kSingleTileShape) flags &= ~CURL_F_TUNE_UNROLL_MASK;
   if (int rc = make_geometry(g, in, out, mask, mask_kind, B, H, W, flags, Op::kUnroll)) return rc;
   StreamArgs a;
   a.in = in;
@@ -782,6 +847,9 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.blocks_per_image = g.blocks_per_image;
   a.n_blocks = g.n_blocks;
   a.no_mem = (flags & CURL_F_DIAG_NO_MEM) ? 1 : 0;
+  a.W = (unsigned)W;
+  a.H = (unsigned)H;
+  a.op_flag = op_flag;
   hipError_t e;
   if constexpr (Op::kMask) {
     e = (mask_kind == CURL_MASK_U8)    ? launch_v<Op, CURL_MASK_U8>(g, a, s)
@@ -1078,6 +1146,38 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind, const 
   hipLaunchKernelGGL(knots_bwd_kernel, dim3(B), dim3(256), 0, s, kb);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "knots_bwd_kernel");
+  return 0;
+}
+
+int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int B, int H, int W, int num_coeffs,
+                          unsigned flags, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!coeffs) return fail(CURL_E_NULL, "coeffs is NULL");
+  if (num_coeffs != 126 && num_coeffs != 35)
+    return fail(CURL_E_KNOTS, "num_coeffs must be 126 (degree 4, 5 variables) or 35 (degree 4, 3 variables)");
+  if (int rc = check_flags(flags, CURL_F_RESIDUAL_ONLY)) return rc;
+  int ro = (flags & CURL_F_RESIDUAL_ONLY) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (num_coeffs == 126)
+    return launch_stream<OpTriSpace<5>>(img, out, nullptr, 0, coeffs, 9 * 126, B, H, W, flags, s, "trispace", ro);
+  return launch_stream<OpTriSpace<3>>(img, out, nullptr, 0, coeffs, 9 * 35, B, H, W, flags, s, "trispace", ro);
+}
+
+int curl_poly_layer_f32(const float* img, const float* coeffs, float* out, int B, int H, int W, int num_variables,
+                        curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!coeffs) return fail(CURL_E_NULL, "coeffs is NULL");
+  if (num_variables != 5 && num_variables != 3) return fail(CURL_E_SHAPE, "num_variables must be 5 or 3 (degree 4)");
+  unsigned HW = (unsigned)((size_t)H * W);
+  dim3 grid((HW + 255u) / 256u, (unsigned)B), block(256);
+  if (num_variables == 5)
+    hipLaunchKernelGGL(poly_layer_kernel<5>, grid, block, 0, (hipStream_t)stream, img, coeffs, out, HW);
+  else
+    hipLaunchKernelGGL(poly_layer_kernel<3>, grid, block, 0, (hipStream_t)stream, img, coeffs, out, HW);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "poly_layer_kernel");
   return 0;
 }
 

@@ -1,0 +1,190 @@
+// curl_math_poly.h -- the polynomial per-pixel path of the reference's live model:
+// ChannelPolyLayer / Deg4MobilePolyLayer (model.py:206-415) and TriSpaceRegNet.generate_residual +
+// generate_image (model.py:499-520).  Same dual compilation as curl_math.h.
+//
+// Per pixel and colour space: 3 outputs, each a polynomial of total degree <= 4 in V = 5 variables (3 colour
+// channels + x/W + y/H; 126 coefficients) or V = 3 (35).  Evaluated in multivariate Horner form
+// (poly_horner.inc, generated): 125 FMAs per output instead of 121 shared multiplies + 126 FMAs.  On gfx950
+// the value type is a packed pair of pixels (v_pk_fma_f32) and the coefficients are wave-uniform: they are
+// read through a uniform pointer, i.e. scalar loads into SGPRs that feed the packed FMAs directly.
+// ~2.6 kFLOP per pixel: this kernel is VALU-bound by a wide margin (no MFMA shape fits: the contraction has
+// 3 output columns per 126-deep dot product, 3/16 of the smallest f32 MFMA tile, at the VALU's own rate).
+#pragma once
+#include "curl_math.h"
+
+namespace curlm {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+CURL_HD curl_f2 poly_fma(curl_f2 a, curl_f2 v, float c) { return __builtin_elementwise_fma(a, v, splat2(c)); }
+CURL_HD curl_f2 poly_fmav(curl_f2 a, curl_f2 v, curl_f2 q) { return __builtin_elementwise_fma(a, v, q); }
+CURL_HD void poly_splat(curl_f2& d, float c) { d = splat2(c); }
+#endif
+CURL_HD float poly_fma(float a, float v, float c) { return fmaf(a, v, c); }
+CURL_HD float poly_fmav(float a, float v, float q) { return fmaf(a, v, q); }
+CURL_HD void poly_splat(float& d, float c) { d = c; }
+
+template <class F>
+CURL_HD F poly_make(float c) {
+  F d;
+  poly_splat(d, c);
+  return d;
+}
+#define CURL_POLY_SPLAT(c) poly_make<F>(c)
+#define CURL_POLY_FMA(a, v, c) poly_fma(a, v, c)
+#define CURL_POLY_FMAV(a, v, q) poly_fmav(a, v, q)
+#include "poly_horner.inc"
+#undef CURL_POLY_SPLAT
+#undef CURL_POLY_FMA
+#undef CURL_POLY_FMAV
+
+template <int V>
+struct PolyEval;
+template <>
+struct PolyEval<5> {
+  static constexpr int kCoeffs = 126;
+  template <class F>
+  static CURL_HD F eval(const F (&v)[5], const float* c) { return poly_d4_v5<F>(v, c); }
+};
+template <>
+struct PolyEval<3> {
+  static constexpr int kCoeffs = 35;
+  template <class F>
+  static CURL_HD F eval(const F (&v)[3], const float* c) { return poly_d4_v3<F>(v, c); }
+};
+
+// out[o][i] = P_o(vars[.][i]) for the N pixels of a lane; coef = [3][NC] of one image and one space.
+// vars is plane-major [V][N].
+template <int V, int N>
+CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float* coef) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) {
+    curl_f2 v[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      v[k].x = vars[k][i];
+      v[k].y = vars[k][i + 1];
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      curl_f2 r = PolyEval<V>::template eval<curl_f2>(v, coef + o * NC);
+      out[o][i] = r.x;
+      out[o][i + 1] = r.y;
+    }
+  }
+  if (N & 1) {
+    float v[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = vars[k][N - 1];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) out[o][N - 1] = PolyEval<V>::template eval<float>(v, coef + o * NC);
+  }
+#else
+  for (int i = 0; i < N; ++i) {
+    float v[V];
+    for (int k = 0; k < V; ++k) v[k] = vars[k][i];
+    for (int o = 0; o < 3; ++o) out[o][i] = PolyEval<V>::template eval<float>(v, coef + o * NC);
+  }
+#endif
+}
+
+// torch.sigmoid over M values: 1 / (1 + exp(-x)); exps and reciprocals in runs
+template <int M>
+CURL_HD void sigmoid_run(float (&x)[M]) {
+  scale_run(x, x, (float)(-1.4426950408889634));  // -log2(e)
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] = hw_exp2(x[i]);
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] = 1.0f + x[i];
+  CURL_FENCE();
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] = rcp_refined(x[i]);
+  CURL_FENCE();
+}
+
+// TriSpaceRegNet.generate_residual (model.py:499-515) [+ generate_image (model.py:517-520) unless residual_only]
+// for the N pixels of a lane.  p: RGB in, result out.  xw, yh: x/width and y/height of each pixel
+// (cat_coords, model.py:487-497; unused when V == 3).  coef: [3 spaces = R, L, H][3][NC] of this image.
+template <int V, int N>
+CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], const float* coef, bool residual_only) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+  PxN<N> lab = p, hsv = p;
+  rgb2lab_n<N>(lab);
+  rgb2hsv_n<N>(hsv);
+  float vars[V][N], o[3][N];
+  float res[3][N];
+  auto fill = [&](const PxN<N>& q) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      vars[0][i] = q.c0[i];
+      vars[1][i] = q.c1[i];
+      vars[2][i] = q.c2[i];
+      if (V == 5) {
+        vars[V - 2][i] = xw[i];
+        vars[V - 1][i] = yh[i];
+      }
+    }
+  };
+  auto squash = [&]() {  // sigmoid over the 3N outputs
+    float flat[3 * N];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) flat[c * N + i] = o[c][i];
+    sigmoid_run(flat);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) o[c][i] = flat[c * N + i];
+  };
+  // RGB space: rgb_res = sigmoid(poly(cat(rgb, x, y), R)); 2 * (rgb_res - 0.5)
+  fill(p);
+  poly3_n<V, N>(o, vars, coef);
+  squash();
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) res[c][i] = 2.0f * (o[c][i] - 0.5f);
+  // Lab space: lab2rgb(sigmoid(poly(cat(lab, x, y), L)))
+  fill(lab);
+  poly3_n<V, N>(o, vars, coef + 3 * NC);
+  squash();
+  {
+    PxN<N> q;
+#pragma unroll
+    for (int i = 0; i < N; ++i) q.c0[i] = o[0][i], q.c1[i] = o[1][i], q.c2[i] = o[2][i];
+    lab2rgb_n<N>(q);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      res[0][i] += 2.0f * (q.c0[i] - 0.5f);
+      res[1][i] += 2.0f * (q.c1[i] - 0.5f);
+      res[2][i] += 2.0f * (q.c2[i] - 0.5f);
+    }
+  }
+  // HSV space: hsv2rgb(sigmoid(poly(cat(hsv, x, y), H)))
+  fill(hsv);
+  poly3_n<V, N>(o, vars, coef + 6 * NC);
+  squash();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Px q = hsv2rgb(Px{o[0][i], o[1][i], o[2][i]});
+    res[0][i] += 2.0f * (q.c0 - 0.5f);
+    res[1][i] += 2.0f * (q.c1 - 0.5f);
+    res[2][i] += 2.0f * (q.c2 - 0.5f);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (residual_only) {  // is_train=False: final_op returns the residual (model.py:485)
+      p.c0[i] = res[0][i], p.c1[i] = res[1][i], p.c2[i] = res[2][i];
+    } else {  // generate_image: clamp(img + residual, 0, 1)
+      p.c0[i] = clamp01(p.c0[i] + res[0][i]);
+      p.c1[i] = clamp01(p.c1[i] + res[1][i]);
+      p.c2[i] = clamp01(p.c2[i] + res[2][i]);
+    }
+  }
+}
+
+}  // namespace curlm

@@ -226,6 +226,43 @@ def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_i
     return g_img, gL, gR, gH
 
 
+# ------------------------------------------------------------------ polynomial path (model.py:206-520)
+def trispace_forward(img, coeffs, residual_only=False, flags=0):
+    """TriSpaceRegNet.generate_residual (+ generate_image unless residual_only), model.py:499-520, in one pass.
+    coeffs [B,3,3,NC] with NC = 126 (spatial) or 35; [:,0]=R, [:,1]=L, [:,2]=H (model.py:526)."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, H, W = img.shape
+    _need_device(coeffs, "coeffs")
+    if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
+        raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
+    c = coeffs.to(torch.float32).contiguous()
+    out = torch.empty_like(img)
+    rc = lib.curl_trispace_fwd_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, c.shape[3],
+                                   flags | (_lib.F_RESIDUAL_ONLY if residual_only else 0), _stream(img))
+    _lib.check(rc, "curl_trispace_fwd_f32")
+    return out
+
+
+def poly_layer(img, coeffs):
+    """ChannelPolyLayer(degree=4) / Deg4MobilePolyLayer forward (model.py:295-333, 399-415):
+    img [B,V,H,W] with V = 5 or 3, coeffs [B,3,126|35] -> [B,3,H,W]."""
+    lib = _lib.load()
+    _need_device(img, "img")
+    _need_device(coeffs, "coeffs")
+    if img.dim() != 4 or img.shape[1] not in (3, 5) or img.dtype != torch.float32:
+        raise ValueError(f"img must be float32 [B,3|5,H,W], got {tuple(img.shape)} {img.dtype}")
+    B, V, H, W = img.shape
+    nc = 126 if V == 5 else 35
+    if tuple(coeffs.shape) != (B, 3, nc):
+        raise ValueError(f"coeffs must be [B={B},3,{nc}], got {tuple(coeffs.shape)}")
+    img, c = img.contiguous(), coeffs.to(torch.float32).contiguous()
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
+    _lib.check(lib.curl_poly_layer_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, V, _stream(img)),
+               "curl_poly_layer_f32")
+    return out
+
+
 # ------------------------------------------------------------------ layout edges
 def u8hwc_to_f32chw(x):
     """uint8 [B,H,W,3|4] (or [H,W,C]) -> float32 [B,3,H,W] = value/255 (infer.py:35-40, transpose.py:19-31)."""

@@ -57,6 +57,8 @@ enum {
                                    affine form a + b*x.  apply_curve / adjust_* only. */
 #define CURL_F_PWL 0x2u         /* paper-style piecewise-linear curve (clamp (S*x-j) to [0,1]) -- NOT the
                                    reference's arithmetic; explicit non-parity option.  adjust_* and layer. */
+#define CURL_F_RESIDUAL_ONLY 0x4u /* curl_trispace_fwd_f32: write the residual instead of clamp(img + residual)
+                                    (TriSpaceRegNet with is_train=False, model.py:485) */
 /* tuning bits (0 = library default; used by the bench sweep, never change results) */
 #define CURL_F_TUNE_UNROLL_SHIFT 8 /* bits 8..10: float4 groups per thread, 0 = default */
 #define CURL_F_TUNE_UNROLL_MASK 0x700u
@@ -134,6 +136,20 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind,
                        void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                        int B, int H, int W, int Kl, int Kr, int Kh,
                        unsigned flags, curl_stream_t stream);
+
+/* replaces: TriSpaceRegNet.generate_residual + generate_image  model.py:499-520 -- the per-pixel path of the
+ *           fork's live model (infer.py:44-45, main.py:283) -- with polylayer = Deg4MobilePolyLayer
+ *           (model.py:336-415) or ChannelPolyLayer(degree=4) (model.py:206-333), as ONE pass over the pixels.
+ * coeffs [B,3,3,num_coeffs] = the reshaped head output (model.py:523-526; [:,0]=R, [:,1]=L, [:,2]=H).
+ * num_coeffs 126 = spatial model (5 variables: colour + x/W + y/H), 35 = non-spatial (3 variables).
+ * Default output: clamp(img + residual, 0, 1); with CURL_F_RESIDUAL_ONLY the residual itself. */
+int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
+                          int num_coeffs, unsigned flags, curl_stream_t stream);
+
+/* replaces: ChannelPolyLayer(degree=4).forward / Deg4MobilePolyLayer.forward  model.py:295-333, 399-415
+ * img [B,num_variables,H,W] (num_variables 5 or 3), coeffs [B,3,num_coeffs] -> out [B,3,H,W]. */
+int curl_poly_layer_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
+                        int num_variables, curl_stream_t stream);
 
 /* replaces: PIL + TF.to_tensor + transpose.swapimdims_HW3_3HW at the file edge
  *           infer.py:35-40, data.py:133-158, transpose.py:19-31

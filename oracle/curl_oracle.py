@@ -329,3 +329,83 @@ def affine_coefficients(C):
     a = C32[:, 0].to(torch.float64) - (seg * j).sum(1)
     b = S * seg.sum(1)
     return a, b
+
+
+# ---------------------------------------------------------------------------
+# model.py:206-415, 499-520 : the polynomial layers and TriSpaceRegNet's per-pixel residual
+# ---------------------------------------------------------------------------
+def poly_powers(degree, num_variables):
+    """Exponent table in the order of ChannelPolyLayer.generate_powers (model.py:222-246): graded, and inside
+    one degree lexicographic with variable 0 most significant.  [num_coeffs, num_variables]."""
+    import itertools
+    rows = []
+    for total in range(degree + 1):
+        ts = [t for t in itertools.product(range(total + 1), repeat=num_variables) if sum(t) == total]
+        ts.sort(reverse=True)
+        rows.extend(ts)
+    return torch.tensor(rows, dtype=torch.float)
+
+
+def channel_poly_layer(img, coeffs, degree):
+    """ChannelPolyLayer.forward (model.py:295-333): img [B,V,H,W], coeffs [B,num_out,num_coeffs]."""
+    V = img.shape[1]
+    pw = poly_powers(degree, V).to(img.dtype)
+    n = pw.shape[0]
+    img_us = torch.unsqueeze(img, dim=0)
+    terms = torch.permute(torch.pow(img_us, pw.reshape(n, 1, V, 1, 1)), [1, 2, 3, 4, 0]).prod(dim=1)
+    return (coeffs.reshape(img.shape[0], coeffs.shape[1], 1, 1, n) * torch.unsqueeze(terms, dim=1)).sum(dim=-1)
+
+
+def deg4_mobile_poly_terms(img):
+    """Deg4MobilePolyLayer.poly_terms (model.py:346-397) for img [B,5,H,W]: the 126 monomials built from
+    explicit products / `**k` (torch evaluates x**2 as x*x, x**3 as x*x*x, x**4 through pow), last dim = term."""
+    x = torch.unsqueeze(img, dim=-1)
+    v = [x[:, i] for i in range(5)]
+    cols = []
+    for row in poly_powers(4, 5).to(torch.int64).tolist():
+        factors = [v[i] if p == 1 else v[i] ** p for i, p in enumerate(row) if p > 0]
+        if not factors:
+            cols.append(1.0 + v[0] * 0.0)
+            continue
+        t = factors[0]
+        for f in factors[1:]:
+            t = t * f
+        cols.append(t)
+    return torch.cat(cols, dim=-1)
+
+
+def deg4_mobile_poly_layer(img, coeffs):
+    """Deg4MobilePolyLayer.forward (model.py:399-415): 5 variables, degree 4, 3 outputs."""
+    terms = deg4_mobile_poly_terms(img)
+    return (coeffs.reshape(img.shape[0], 3, 1, 1, 126) * torch.unsqueeze(terms, dim=1)).sum(dim=-1)
+
+
+def cat_coords(img, spatial=True):
+    """TriSpaceRegNet.cat_coords (model.py:487-497): append x/width and y/height planes."""
+    if not spatial:
+        return img
+    B, _, H, W = img.shape
+    zeros = img[:, 0:1] * 0.0
+    x = zeros + torch.arange(0, W).reshape(1, 1, 1, W) / W
+    y = zeros + torch.arange(0, H).reshape(1, 1, H, 1) / H
+    return torch.cat([img, x, y], dim=1)
+
+
+def trispace_residual(img, R, L, H, spatial=True, mobile=True):
+    """TriSpaceRegNet.generate_residual (model.py:499-515).  R, L, H: [B,3,num_coeffs]."""
+    def poly(x, c):
+        if spatial and mobile:
+            return deg4_mobile_poly_layer(x, c)
+        return channel_poly_layer(x, c, 4)
+    rgb_res = torch.sigmoid(poly(cat_coords(img, spatial), R))
+    lab_res = lab2rgb(torch.sigmoid(poly(cat_coords(rgb2lab(img), spatial), L)))
+    hsv_res = hsv2rgb(torch.sigmoid(poly(cat_coords(rgb2hsv(img), spatial), H)))
+    rgb_res = 2 * (rgb_res - 0.5)
+    lab_res = 2 * (lab_res - 0.5)
+    hsv_res = 2 * (hsv_res - 0.5)
+    return rgb_res + lab_res + hsv_res
+
+
+def generate_image(img, residual):
+    """TriSpaceRegNet.generate_image (model.py:517-520)."""
+    return torch.clamp(img + residual, 0.0, 1.0)

@@ -51,10 +51,11 @@ def twin():
     src = os.path.join(ROOT, "tests", "twin", "curl_twin.cpp")
     hdr = os.path.join(ROOT, "curl_amd", "csrc", "curl_math.h")
     hdr2 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_bwd.h")
+    hdr3 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_poly.h")
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libcurl_twin.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2), os.path.getmtime(hdr3)):
         subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
                                "-DCURL_HOST_TWIN", "-Wno-unknown-pragmas", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -114,6 +115,23 @@ def twin():
             lib.twin_layer_bwd(P(img), P(mask), P(L), P(R), P(H), P(gout), P(greg), P(gimg), P(gL), P(gR), P(gH), B,
                                ctypes.c_long(Hh * W), L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4)
             return gimg, gL, gR, gH
+
+        @staticmethod
+        def trispace(img, coeffs, residual_only=False):
+            img, coeffs = f32(img), f32(coeffs)
+            out = np.empty_like(img)
+            B, _, Hh, W = img.shape
+            V = 5 if coeffs.shape[-1] == 126 else 3
+            lib.twin_trispace(P(img), P(coeffs), P(out), B, Hh, W, V, int(residual_only))
+            return out
+
+        @staticmethod
+        def poly_layer(img, coeffs):
+            img, coeffs = f32(img), f32(coeffs)
+            B, V, Hh, W = img.shape
+            out = np.empty((B, 3, Hh, W), np.float32)
+            lib.twin_poly_layer(P(img), P(coeffs), P(out), B, ctypes.c_long(Hh * W), V)
+            return out
 
     return Twin
 

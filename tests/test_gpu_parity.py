@@ -437,3 +437,42 @@ def test_infer_cli_end_to_end(dev, tmp_path):
     assert out.shape == (H, W, 3) and out.dtype == np.uint8
     assert (out[mask == 0] == 255).all()
     assert out[mask == 255].std() > 0
+
+
+# ------------------------------------------------------------------ polynomial path
+@pytest.mark.parametrize("s,tol", [("s02", 1e-5), ("s1", 2e-5)])
+def test_trispace_golden(ops, dev, golden, s, tol):
+    """TriSpaceRegNet.generate_residual / generate_image (model.py:499-520) vs outputs of the reference's classes."""
+    g = golden("poly")
+    c = T(g[s + "_coeffs"], dev)
+    for nm in ("img", "img8"):
+        x = T(g[nm], dev)
+        assert max_err(N(ops.trispace_forward(x, c, residual_only=True)), g[f"{s}_{nm}_residual"]) <= tol, nm
+        assert max_err(N(ops.trispace_forward(x, c)), g[f"{s}_{nm}_image"]) <= tol, nm
+    c35 = T(g[s + "_coeffs35"], dev)
+    assert max_err(N(ops.trispace_forward(T(g["img"], dev), c35, residual_only=True)),
+                   g[f"{s}_img_residual_nonspatial"]) <= tol
+
+
+def test_poly_layer_golden(ops, dev, golden):
+    g = golden("poly")
+    assert max_err(N(ops.poly_layer(T(g["x5"], dev), T(g["c5"], dev))), g["mobile_poly"]) <= 3e-6
+    assert max_err(N(ops.poly_layer(T(g["x5"], dev), T(g["c5"], dev))), g["channel_poly_d4v5"]) <= 3e-6
+    assert max_err(N(ops.poly_layer(T(g["x3"], dev), T(g["c3"], dev))), g["channel_poly_d4v3"]) <= 3e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 7, 9), (2, 30, 50), (1, 64, 100)])
+def test_trispace_shapes_vs_oracle(ops, dev, shape):
+    """Coordinates (x/W, y/H) must follow the pixel through scalar / float4 kernels, W % 4 != 0 included."""
+    import curl_oracle as O
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    img = torch.rand(B, 3, H, W, generator=g)
+    c = torch.randn(B, 3, 3, 126, generator=g) * 0.3
+    c[:, :, :, 4] = 3.0   # make the x/W coefficient matter: a coordinate mix-up shows as a ramp error
+    c[:, :, :, 5] = -2.0  # y/H
+    ref = O.trispace_residual(img, c[:, 0], c[:, 1], c[:, 2])
+    out = ops.trispace_forward(img.to(dev), c.to(dev), residual_only=True)
+    assert max_err(N(out), ref.numpy()) <= 1e-5
+    full = ops.trispace_forward(img.to(dev), c.to(dev))
+    assert max_err(N(full), O.generate_image(img, ref).numpy()) <= 1e-5

@@ -1,0 +1,61 @@
+"""The polynomial per-pixel path: oracle vs the golden vectors produced by running the
+reference's own classes, the kernel arithmetic (host twin) vs both."""
+import numpy as np
+import pytest
+import torch
+
+import curl_oracle as O
+from conftest import max_err
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_power_table_matches_reference(golden):
+    g = golden("poly")
+    for d, v in ((4, 5), (4, 3), (3, 2)):
+        assert np.array_equal(O.poly_powers(d, v).numpy().astype(np.int32), g[f"powers_d{d}_v{v}"])
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT + "/tools")
+    from gen_poly_horner import powers
+    assert [list(r) for r in powers(4, 5)] == g["powers_d4_v5"].tolist()  # the generated Horner code's indexing
+
+
+def test_oracle_poly_layers_golden(golden):
+    g = golden("poly")
+    assert np.allclose(O.channel_poly_layer(t(g["x5"]), t(g["c5"]), 4).numpy(), g["channel_poly_d4v5"], rtol=0, atol=2e-6)
+    assert np.allclose(O.deg4_mobile_poly_layer(t(g["x5"]), t(g["c5"])).numpy(), g["mobile_poly"], rtol=0, atol=2e-6)
+    assert np.allclose(O.channel_poly_layer(t(g["x3"]), t(g["c3"]), 4).numpy(), g["channel_poly_d4v3"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("s", ["s02", "s1"])
+def test_oracle_trispace_golden(golden, s):
+    g = golden("poly")
+    c = t(g[s + "_coeffs"])
+    for nm in ("img", "img8"):
+        r = O.trispace_residual(t(g[nm]), c[:, 0], c[:, 1], c[:, 2])
+        assert max_err(r.numpy(), g[f"{s}_{nm}_residual"]) <= 3e-6
+        assert max_err(O.generate_image(t(g[nm]), r).numpy(), g[f"{s}_{nm}_image"]) <= 3e-6
+    c35 = t(g[s + "_coeffs35"])
+    r = O.trispace_residual(t(g["img"]), c35[:, 0], c35[:, 1], c35[:, 2], spatial=False)
+    assert max_err(r.numpy(), g[f"{s}_img_residual_nonspatial"]) <= 3e-6
+
+
+def test_twin_poly_layer(twin, golden):
+    """Horner form vs the reference's sum of monomials: same polynomial, different rounding; the two reference
+    layers themselves differ by 1e-6 at this coefficient scale (model.py:404-409 claims equality)."""
+    g = golden("poly")
+    assert max_err(twin.poly_layer(g["x5"], g["c5"]), g["mobile_poly"]) <= 3e-6
+    assert max_err(twin.poly_layer(g["x5"], g["c5"]), g["channel_poly_d4v5"]) <= 3e-6
+    assert max_err(twin.poly_layer(g["x3"], g["c3"]), g["channel_poly_d4v3"]) <= 3e-6
+
+
+@pytest.mark.parametrize("s,tol", [("s02", 1e-5), ("s1", 2e-5)])
+def test_twin_trispace(twin, golden, s, tol):
+    g = golden("poly")
+    for nm in ("img", "img8"):
+        assert max_err(twin.trispace(g[nm], g[s + "_coeffs"], residual_only=True), g[f"{s}_{nm}_residual"]) <= tol, nm
+        assert max_err(twin.trispace(g[nm], g[s + "_coeffs"]), g[f"{s}_{nm}_image"]) <= tol, nm
+    assert max_err(twin.trispace(g["img"], g[s + "_coeffs35"], residual_only=True), g[f"{s}_img_residual_nonspatial"]) <= tol

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../curl_amd/csrc/curl_math_bwd.h"
+#include "../../curl_amd/csrc/curl_math_poly.h"
 
 using namespace curlm;
 
@@ -164,6 +165,44 @@ int twin_layer_bwd(const float* img, const float* mask, const float* rawL, const
     for (int c = 0; c < 3; ++c) knots_bwd(kr.data() + c * Kr, Kr, P[3 + c], Q[3 + c], gr, gR + (size_t)b * 3 * Kr + c * Kr);
     for (int c = 0; c < 4; ++c) knots_bwd(kh.data() + c * Kh, Kh, P[6 + c], Q[6 + c], gr, gH + (size_t)b * 4 * Kh + c * Kh);
   }
+  return 0;
+}
+
+// TriSpaceRegNet per-pixel path. coeffs [B,3,3,NC] (R,L,H); V = 5 (spatial) or 3.
+int twin_trispace(const float* img, const float* coeffs, float* out, int B, int H, int W, int V, int residual_only) {
+  const long HW = (long)H * W;
+  const int NC = V == 5 ? 126 : 35;
+  for (int b = 0; b < B; ++b)
+    for (long i = 0; i < HW; ++i) {
+      const float* p = img + (size_t)b * 3 * HW + i;
+      PxN<1> q{{p[0]}, {p[HW]}, {p[2 * HW]}};
+      const float xw[1] = {(float)(i % W) / (float)W}, yh[1] = {(float)(i / W) / (float)H};
+      if (V == 5)
+        trispace_n<5, 1>(q, xw, yh, coeffs + (size_t)b * 9 * NC, residual_only != 0);
+      else
+        trispace_n<3, 1>(q, xw, yh, coeffs + (size_t)b * 9 * NC, residual_only != 0);
+      float* o = out + (size_t)b * 3 * HW + i;
+      o[0] = q.c0[0], o[HW] = q.c1[0], o[2 * HW] = q.c2[0];
+    }
+  return 0;
+}
+// ChannelPolyLayer / Deg4MobilePolyLayer forward: img [B,V,H,W], coeffs [B,3,NC] -> out [B,3,H,W]
+int twin_poly_layer(const float* img, const float* coeffs, float* out, int B, long HW, int V) {
+  const int NC = V == 5 ? 126 : 35;
+  for (int b = 0; b < B; ++b)
+    for (long i = 0; i < HW; ++i) {
+      float o[3][1];
+      if (V == 5) {
+        float v[5][1];
+        for (int k = 0; k < 5; ++k) v[k][0] = img[((size_t)b * 5 + k) * HW + i];
+        poly3_n<5, 1>(o, v, coeffs + (size_t)b * 3 * NC);
+      } else {
+        float v[3][1];
+        for (int k = 0; k < 3; ++k) v[k][0] = img[((size_t)b * 3 + k) * HW + i];
+        poly3_n<3, 1>(o, v, coeffs + (size_t)b * 3 * NC);
+      }
+      for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + i] = o[c][0];
+    }
   return 0;
 }
 }
