@@ -21,6 +21,10 @@
 
 using namespace curlm;
 
+#ifndef CURL_TRISPACE_WAVES
+#define CURL_TRISPACE_WAVES 4  // register budget of the polynomial kernel: 128 VGPRs (it needs ~106)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
@@ -286,13 +290,22 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
 }
 
 template <class Op, int VEC, int U, int MK, bool NT>
-__global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(256, Op::kMinWavesPerSimd) void stream_kernel(StreamArgs a) {
   typedef typename Pack<VEC>::T T;
   // grid = (chunks per image, images): both indices are SGPRs, no division
   const unsigned img = blockIdx.y;
   const unsigned chunk = blockIdx.x;
   __builtin_assume(a.n <= (1u << 28));  // H*W <= 2^30 (checked on the host): byte offsets fit 32 bits
-  const typename Op::K k = Op::load(a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr, a);
+  const float* table = a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr;
+  __shared__ float s_table[Op::kLdsFloats > 0 ? Op::kLdsFloats : 1];
+  if constexpr (Op::kLdsFloats > 0) {
+    // a per-image table too large for SGPRs (1134 polynomial coefficients): one coalesced copy into LDS, then
+    // every lane reads the same address (broadcast ds_read_b128, conflict-free)
+    for (int i = threadIdx.x; i < Op::kLdsFloats; i += 256) s_table[i] = table[Op::stage_index(i)];
+    __syncthreads();
+    table = s_table;
+  }
+  const typename Op::K k = Op::load(table, a);
   const size_t plane = (size_t)a.n;
   const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
   T* q0 = reinterpret_cast<T*>(a.out) + (size_t)img * 3 * plane;
@@ -309,6 +322,8 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
 struct NoK {};
 struct OpDefaults {
   static constexpr bool kSingleTileShape = false;
+  static constexpr int kLdsFloats = 0;  // per-image table the block stages in LDS before the tile (0 = none)
+  static constexpr int kMinWavesPerSimd = 1;  // __launch_bounds__ second argument (register budget)
 };
 #define CONVERTER_OP(NAME, FN)                                                           \
   struct NAME : OpDefaults {                                                             \
@@ -420,10 +435,12 @@ struct OpLayer : OpDefaults {
 };
 
 // TriSpaceRegNet.generate_residual (+ generate_image), model.py:499-520: three degree-4 polynomial layers in
-// RGB / Lab / HSV + converters, one pass.  The 9 x NC coefficients of the image stay behind a uniform pointer:
-// the Horner code reads them with scalar loads straight into the SGPR operand of the packed FMAs.
+// RGB / Lab / HSV + converters, one pass.  The 9 x NC coefficients of the image are staged in LDS by the block
+// (kLdsFloats) and reach the packed FMAs as broadcast ds_read_b128 -> VGPR halves (op_sel).  Reading them
+// through a uniform global pointer instead made hipcc hoist all 1134 scalar loads and spill SGPRs into VGPR
+// lanes (3000 v_readlane/v_writelane per thread, 4.4 ms per batch).
 template <int V>
-struct OpTriSpace {
+struct OpTriSpace : OpDefaults {
   struct K {
     const float* coef;
     unsigned W;
@@ -433,6 +450,14 @@ struct OpTriSpace {
   static constexpr bool kMask = false;
   static constexpr int kUnroll = 1;
   static constexpr bool kSingleTileShape = true;
+  static constexpr int kLdsFloats = 9 * PolyEval<V>::kCoeffs;
+  static constexpr int kMinWavesPerSimd = CURL_TRISPACE_WAVES;
+  // LDS position p of polynomial q holds the coefficient the Horner scheme consumes p-th
+  static __device__ __forceinline__ int stage_index(int i) {
+    constexpr int NC = PolyEval<V>::kCoeffs;
+    int q = i / NC, pos = i - q * NC;
+    return q * NC + PolyEval<V>::order(pos);
+  }
   static constexpr bool kBlendMaskedOut = false;
   static __device__ __forceinline__ K load(const float* coef_img, const StreamArgs& a) {
     return K{coef_img, a.W, (float)a.W, (float)a.H, a.op_flag != 0};
@@ -449,7 +474,7 @@ struct OpTriSpace {
         if (++col == k.W) col = 0, ++row;
       }
     }
-    trispace_n<V, N>(p, xw, yh, k.coef, k.residual_only);
+    trispace_n<V, N, true>(p, xw, yh, k.coef, k.residual_only);
   }
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };

@@ -42,49 +42,68 @@ struct PolyEval;
 template <>
 struct PolyEval<5> {
   static constexpr int kCoeffs = 126;
-  template <class F>
-  static CURL_HD F eval(const F (&v)[5], const float* c) { return poly_d4_v5<F>(v, c); }
+  template <class F, bool SEQ, int NP>
+  static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][5], const float* c) { poly_d4_v5<F, SEQ, NP>(out, v, c); }
+  static CURL_HD int order(int pos) { return kPolyOrder_d4_v5[pos]; }
 };
 template <>
 struct PolyEval<3> {
   static constexpr int kCoeffs = 35;
-  template <class F>
-  static CURL_HD F eval(const F (&v)[3], const float* c) { return poly_d4_v3<F>(v, c); }
+  template <class F, bool SEQ, int NP>
+  static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][3], const float* c) { poly_d4_v3<F, SEQ, NP>(out, v, c); }
+  static CURL_HD int order(int pos) { return kPolyOrder_d4_v3[pos]; }
 };
 
-// out[o][i] = P_o(vars[.][i]) for the N pixels of a lane; coef = [3][NC] of one image and one space.
-// vars is plane-major [V][N].
-template <int V, int N>
+// out[o][i] = P_o(vars[.][i]) for the N pixels of a lane; coef = [3][NC] of one image and one space, in the
+// reference's order (SEQ = false) or permuted into Horner consumption order (SEQ = true).  vars is plane-major.
+template <int V, int N, bool SEQ = false>
 CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float* coef) {
   constexpr int NC = PolyEval<V>::kCoeffs;
 #if defined(__HIP_DEVICE_COMPILE__)
+  // One output polynomial at a time, all pixel pairs of the lane in lock step (poly_horner.inc): the pairs share
+  // every coefficient read (one broadcast ds_read_b128 feeds 4 terms x N/2 packed FMAs) and are the ILP of the
+  // Horner chain; fences inside the generated code bound how far ahead the reads are hoisted (unfenced, hipcc
+  // hoisted them all, needed > 256 VGPRs and spilled).
+  constexpr int NP = N / 2;
+  if constexpr (NP > 0) {
+    curl_f2 v[NP][V], r[NP];
 #pragma unroll
-  for (int i = 0; i + 1 < N; i += 2) {
-    curl_f2 v[V];
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-      v[k].x = vars[k][i];
-      v[k].y = vars[k][i + 1];
-    }
+      for (int k = 0; k < V; ++k) {
+        v[q][k].x = vars[k][2 * q];
+        v[q][k].y = vars[k][2 * q + 1];
+      }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-      curl_f2 r = PolyEval<V>::template eval<curl_f2>(v, coef + o * NC);
-      out[o][i] = r.x;
-      out[o][i + 1] = r.y;
+      CURL_FENCE();
+      PolyEval<V>::template eval<curl_f2, SEQ, NP>(r, v, coef + o * NC);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        out[o][2 * q] = r[q].x;
+        out[o][2 * q + 1] = r[q].y;
+      }
     }
+    CURL_FENCE();
   }
   if (N & 1) {
-    float v[V];
+    float vs[1][V], rs[1];
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = vars[k][N - 1];
+    for (int k = 0; k < V; ++k) vs[0][k] = vars[k][N - 1];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) out[o][N - 1] = PolyEval<V>::template eval<float>(v, coef + o * NC);
+    for (int o = 0; o < 3; ++o) {
+      PolyEval<V>::template eval<float, SEQ, 1>(rs, vs, coef + o * NC);
+      out[o][N - 1] = rs[0];
+    }
   }
 #else
   for (int i = 0; i < N; ++i) {
-    float v[V];
-    for (int k = 0; k < V; ++k) v[k] = vars[k][i];
-    for (int o = 0; o < 3; ++o) out[o][i] = PolyEval<V>::template eval<float>(v, coef + o * NC);
+    float v[1][V], r[1];
+    for (int k = 0; k < V; ++k) v[0][k] = vars[k][i];
+    for (int o = 0; o < 3; ++o) {
+      PolyEval<V>::template eval<float, SEQ, 1>(r, v, coef + o * NC);
+      out[o][i] = r[0];
+    }
   }
 #endif
 }
@@ -108,7 +127,7 @@ CURL_HD void sigmoid_run(float (&x)[M]) {
 // TriSpaceRegNet.generate_residual (model.py:499-515) [+ generate_image (model.py:517-520) unless residual_only]
 // for the N pixels of a lane.  p: RGB in, result out.  xw, yh: x/width and y/height of each pixel
 // (cat_coords, model.py:487-497; unused when V == 3).  coef: [3 spaces = R, L, H][3][NC] of this image.
-template <int V, int N>
+template <int V, int N, bool SEQ = false>
 CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], const float* coef, bool residual_only) {
   constexpr int NC = PolyEval<V>::kCoeffs;
   PxN<N> lab = p, hsv = p;
@@ -142,7 +161,7 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
   };
   // RGB space: rgb_res = sigmoid(poly(cat(rgb, x, y), R)); 2 * (rgb_res - 0.5)
   fill(p);
-  poly3_n<V, N>(o, vars, coef);
+  poly3_n<V, N, SEQ>(o, vars, coef);
   squash();
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -150,7 +169,7 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
     for (int i = 0; i < N; ++i) res[c][i] = 2.0f * (o[c][i] - 0.5f);
   // Lab space: lab2rgb(sigmoid(poly(cat(lab, x, y), L)))
   fill(lab);
-  poly3_n<V, N>(o, vars, coef + 3 * NC);
+  poly3_n<V, N, SEQ>(o, vars, coef + 3 * NC);
   squash();
   {
     PxN<N> q;
@@ -166,7 +185,7 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
   }
   // HSV space: hsv2rgb(sigmoid(poly(cat(hsv, x, y), H)))
   fill(hsv);
-  poly3_n<V, N>(o, vars, coef + 6 * NC);
+  poly3_n<V, N, SEQ>(o, vars, coef + 6 * NC);
   squash();
 #pragma unroll
   for (int i = 0; i < N; ++i) {

@@ -31,25 +31,27 @@ def gen(degree, nvars):
     index = {t: i for i, t in enumerate(table)}
     counter = [0]
     lines = []
+    order = []  # consumption order: position -> reference coefficient index
+
+    def coef(exps):
+        order.append(index[tuple(exps)])
+        return f"CURL_POLY_C({len(order) - 1})"
 
     def horner(var, max_deg, prefix):
         """returns a C expression (string) for the polynomial in variables var.. with total degree <= max_deg,
-        emitting statements for intermediate accumulators"""
+        emitting statements for intermediate accumulators; coefficients are numbered in the order they are used"""
         if var == nvars:
-            return f"CURL_POLY_C({index[tuple(prefix)]})"
+            return coef(prefix)
         if var == nvars - 1:
-            # univariate tail: plain Horner chain in one accumulator
-            terms = [f"CURL_POLY_C({index[tuple(prefix + [k])]})" for k in range(max_deg + 1)]
+            # univariate tail: plain Horner chain in one accumulator, highest power first
             if max_deg == 0:
-                return terms[0]
+                return coef(prefix + [0])
             name = f"t{counter[0]}"
             counter[0] += 1
-            lines.append(f"  F {name} = CURL_POLY_SPLAT({terms[max_deg]});")
+            lines.append(f"  F {name} = CURL_POLY_SPLAT({coef(prefix + [max_deg])});")
             for k in range(max_deg - 1, -1, -1):
-                lines.append(f"  {name} = CURL_POLY_FMA({name}, v[{var}], {terms[k]});")
+                lines.append(f"  {name} = CURL_POLY_FMA({name}, v[{var}], {coef(prefix + [k])});")
             return name
-        qs = [None] * (max_deg + 1)
-        # evaluate the highest power's cofactor first, then fold
         q_top = horner(var + 1, 0, prefix + [max_deg])
         name = f"t{counter[0]}"
         counter[0] += 1
@@ -66,15 +68,45 @@ def gen(degree, nvars):
         return name
 
     result = horner(0, degree, [])
+    assert sorted(order) == list(range(len(table)))
     n_fma = sum(1 for l in lines if "CURL_POLY_FMA" in l)
-    body = "\n".join(lines)
-    return table, f"""// degree {degree}, {nvars} variables: {len(table)} coefficients, {n_fma} FMAs
-template <class F>
-CURL_HD F poly_d{degree}_v{nvars}(const F (&v)[{nvars}], const float* c) {{
-#define CURL_POLY_C(t) c[t]
+    # lock-step form: every statement runs over the NP pixel groups of the lane (NP independent chains), and a
+    # scheduling fence every FENCE_EVERY statements bounds how far ahead coefficient reads can be hoisted
+    FENCE_EVERY = 12
+    out_lines = []
+    import re
+    n_stmt = 0
+    for l in lines:
+        m = re.match(r"  F (t\d+) = (.*);", l)
+        if m:
+            name, rhs = m.group(1), m.group(2)
+            rhs_p = re.sub(r"\b(t\d+)\b", r"\1[p]", rhs)
+            out_lines.append(f"  F {name}[NP];")
+            out_lines.append(f"  CURL_POLY_EACH {name}[p] = {rhs_p};")
+        else:
+            m = re.match(r"  (t\d+) = (.*);", l)
+            name, rhs = m.group(1), m.group(2)
+            rhs_p = re.sub(r"\b(t\d+)\b", r"\1[p]", rhs).replace("v[", "v[p][")
+            out_lines.append(f"  CURL_POLY_EACH {name}[p] = {rhs_p};")
+            n_stmt += 1
+            if n_stmt % FENCE_EVERY == 0:
+                out_lines.append("  CURL_FENCE();")
+    body = "\n".join(out_lines)
+    tab = ", ".join(str(i) for i in order)
+    return table, f"""// degree {degree}, {nvars} variables: {len(table)} coefficients, {n_fma} FMAs per chain
+// position in the order the Horner scheme consumes them -> coefficient index of the reference (generate_powers)
+constexpr unsigned short kPolyOrder_d{degree}_v{nvars}[{len(table)}] = {{{tab}}};
+// NP chains (pixel groups of one lane) advance in lock step.
+// SEQ = true: c already holds the coefficients in consumption order (the LDS copy: sequential ds_read_b128);
+// SEQ = false: c is the reference's layout, indexed through the (compile-time) table.
+template <class F, bool SEQ, int NP>
+CURL_HD void poly_d{degree}_v{nvars}(F (&out)[NP], const F (&v)[NP][{nvars}], const float* c) {{
+#define CURL_POLY_C(q) (SEQ ? c[q] : c[kPolyOrder_d{degree}_v{nvars}[q]])
+#define CURL_POLY_EACH _Pragma("unroll") for (int p = 0; p < NP; ++p)
 {body}
+  CURL_POLY_EACH out[p] = {result}[p];
+#undef CURL_POLY_EACH
 #undef CURL_POLY_C
-  return {result};
 }}
 """
 
