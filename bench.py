@@ -42,7 +42,8 @@ def make_inputs(B, device, seed, n_sets=2):
         L = (torch.randn(B, 48, generator=g) * 0.1).to(device)
         R = (torch.randn(B, 48, generator=g) * 0.1).to(device)
         Hk = (torch.randn(B, 64, generator=g) * 0.1).to(device)
-        sets.append((img, L, R, Hk))
+        poly = (torch.randn(B, 3, 3, 126, generator=g) * 0.2).to(device)
+        sets.append((img, L, R, Hk, poly))
     return sets
 
 
@@ -55,6 +56,8 @@ WORKLOADS = {
     "lab_stage": ("fused RGB->Lab->3 curves->mask->RGB (the kernel BASELINE's 70 % target names), bool mask all "
                   "ones", 25.0, "OpLabStage", "ones"),
     "rgb_only": ("RGB-only 3 curves (adjust_rgb, BASELINE configs[1]), no mask", 24.0, "OpAdjust3", None),
+    "trispace": ("TriSpaceRegNet per-pixel path (SURVEY 8f-1): 3 x degree-4 polynomial layers (126 coeffs x 3 outputs) in "
+                 "RGB/Lab/HSV + converters + clamp, fused; arithmetic-bound (~2.6 kFLOP/px)", 24.0, "OpTriSpace", None),
 }
 
 
@@ -66,6 +69,8 @@ def make_step(name, ops, masks):
         return lambda s: ops.lab_stage(s[0], mask, s[1])
     if name == "rgb_only":
         return lambda s: ops.adjust_rgb(s[0], s[2])
+    if name == "trispace":
+        return lambda s: ops.trispace_forward(s[0], s[4])
     raise ValueError(name)
 
 

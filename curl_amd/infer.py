@@ -18,8 +18,12 @@ from . import ops
 from .convert_state import convert_state_dict
 
 
-def build_net(model_file, device):
-    net = model_mod.GCURLNet(encoder_size=320)
+def build_net(model_file, device, arch="curl"):
+    if arch == "trispace":  # infer.py:22-23
+        net = model_mod.TriSpaceRegNet(polynomial_order=4, spatial=True, is_train=False,
+                                       polylayer=model_mod.Deg4MobilePolyLayer())
+    else:
+        net = model_mod.GCURLNet(encoder_size=320)
     if model_file != "random":
         ckpt = torch.load(model_file, map_location="cpu")  # infer.py:25
         state = convert_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt)  # infer.py:28
@@ -41,9 +45,13 @@ def encoder_view(img, mask, size=320):
 @torch.no_grad()
 def enhance(net, img_u8, mask_u8, device):
     """img_u8: HxWx3|4 uint8, mask_u8: HxW uint8 ('L').  Returns HxWx3 uint8 (numpy)."""
-    x = ops.u8hwc_to_f32chw(torch.from_numpy(np.ascontiguousarray(img_u8)).to(device)[None])
-    tmask = torch.from_numpy(np.ascontiguousarray(mask_u8)).to(device)[None, None].float() / 255.0  # to_tensor
+    x = ops.u8hwc_to_f32chw(torch.from_numpy(np.array(img_u8)).to(device)[None])
+    tmask = torch.from_numpy(np.array(mask_u8)).to(device)[None, None].float() / 255.0  # to_tensor
     small, msmall = encoder_view(x, tmask)
+    if isinstance(net, model_mod.TriSpaceRegNet):
+        residual = net(small, msmall, x)                        # infer.py:44 (is_train=False -> residual)
+        out = net.generate_image(x, residual)                   # infer.py:45
+        return ops.compose_white_u8hwc(out, tmask)[0].cpu().numpy()  # infer.py:46-47
     knots = net.predict_knots(small * msmall)  # the encoder sees the masked 320x320 view
     L, R, H = knots[:, :net.curve_break_1], knots[:, net.curve_break_1:net.curve_break_2], knots[:, net.curve_break_2:]
     full_mask = torch.ones_like(tmask)  # the reference applies the mask only when compositing (infer.py:44-46)
@@ -57,10 +65,13 @@ def infer(argv=None):
     parser.add_argument("--mask_path", type=str, required=True, help="Path to image to enhancement")
     parser.add_argument("--model_file", type=str, required=True, help="Path to model checkpoint file ('random' = random init)")
     parser.add_argument("--out_path", type=str, required=True, help="Path to write output image to")
+    parser.add_argument("--arch", choices=("trispace", "curl"), default="trispace",
+                        help="trispace = the reference's infer.py model (TriSpaceRegNet + Deg4MobilePolyLayer); "
+                             "curl = the curve model (GCURLNet)")
     args = parser.parse_args(argv)
     from PIL import Image
     device = torch.device("cuda:0")
-    net = build_net(args.model_file, device)
+    net = build_net(args.model_file, device, args.arch)
     img = np.asarray(Image.open(args.img_path))
     if img.ndim == 2:
         img = np.repeat(img[..., None], 3, axis=2)

@@ -162,3 +162,116 @@ class GCURLNet(nn.Module):
             curves[:, self.curve_break_2:]
         img, gradient_regulariser = self.curllayer(img, mask, L, R, H)
         return img, gradient_regulariser
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The polynomial model of the fork: model.py:206-535.  Per-pixel work = ONE fused HIP kernel.
+# ---------------------------------------------------------------------------------------------------------
+def _ncr(n, r):
+    import math
+    return math.comb(n, r)
+
+
+def _powers(degree, num_variables):
+    import itertools
+    rows = []
+    for total in range(degree + 1):
+        ts = [t for t in itertools.product(range(total + 1), repeat=num_variables) if sum(t) == total]
+        ts.sort(reverse=True)
+        rows.extend(ts)
+    return rows
+
+
+class ChannelPolyLayer(nn.Module):
+    """model.py:206-333.  forward(img [B,V,H,W], coeffs [B,num_out,num_coeffs]) -> [B,num_out,H,W].
+    The HIP kernel covers what the fork uses: degree 4, V = 5 or 3, num_out = 3."""
+
+    def __init__(self, degree=3, num_variables=3, num_out=None):
+        assert degree >= 0 and type(degree) == int, "`degree` must be non-negative integer"
+        assert num_variables >= 0 and type(num_variables) == int, "`num_variables` must be non-negative integer"
+        super().__init__()
+        self.degree = degree
+        self.num_variables = num_variables
+        self.num_out = self.num_variables if num_out is None else num_out
+        self.num_coeffs = _ncr(num_variables + degree, degree)
+        self.powers = nn.Parameter(torch.Tensor(_powers(degree, num_variables)), requires_grad=False)  # state-dict key
+
+    @staticmethod
+    def generate_powers(order, n_variables):
+        """Same sequence as the reference's generator (model.py:222-246)."""
+        yield from _powers(order, n_variables)
+
+    def forward(self, img, coeffs):
+        assert img.shape[1] == self.num_variables, "There should be a polynomial variable per channel"
+        assert len(coeffs.shape) == 3 and coeffs.shape[2] == self.num_coeffs, \
+            f"coeffs must be [B, num_out, {self.num_coeffs}]"
+        if self.degree != 4 or self.num_variables not in (3, 5) or self.num_out != 3:
+            raise NotImplementedError("the HIP polynomial kernel is built for degree 4, 3 or 5 variables, 3 outputs "
+                                      "(the configurations model.py:426,450 use)")
+        return ops.poly_layer(img, coeffs)
+
+
+class Deg4MobilePolyLayer(nn.Module):
+    """model.py:336-415: ChannelPolyLayer(degree=4, num_variables=5, num_out=3) written out for CoreML."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_coeffs = 126
+        self.powers = nn.Parameter(torch.Tensor(_powers(4, 5)), requires_grad=False)
+
+    def forward(self, img, coeffs):
+        return ops.poly_layer(img, coeffs.reshape(img.shape[0], 3, self.num_coeffs))
+
+
+class TriSpaceRegNet(nn.Module):
+    """model.py:439-535: encoder -> [B,3,3,num_coeffs] -> per-pixel degree-4 polynomials in RGB, Lab and HSV.
+    generate_residual + generate_image run as one fused kernel (ops.trispace_forward).
+    The reference's backbone is timm `efficientnetv2_rw_t` (not installed here, needs a download); any module
+    with a `.classifier` whose pooled feature width is `feature_width` can be injected."""
+
+    def __init__(self, polynomial_order=4, spatial=False, max_resolution=10000, is_train=True, use_sync_bn=False,
+                 polylayer=None, backbone=None, feature_width=1024):
+        super().__init__()
+        self.num_channels = 3
+        self.num_spaces = 3
+        self.num_in = self.num_channels + 2 * spatial
+        self.order = polynomial_order
+        self.is_train = is_train
+        self.max_resolution = max_resolution
+        self.polylayer = polylayer if polylayer is not None else ChannelPolyLayer(
+            degree=self.order, num_variables=self.num_in, num_out=self.num_channels)
+        self.num_coeffs = self.polylayer.num_coeffs
+        if self.order != 4 or self.num_coeffs not in (126, 35):
+            raise NotImplementedError("fused kernel: polynomial_order 4 with spatial=True (126) or False (35)")
+        if backbone is None:
+            backbone = CurveEncoder(num_outputs=1, num_features=feature_width)
+        if use_sync_bn:
+            backbone = nn.SyncBatchNorm.convert_sync_batchnorm(backbone)  # model.py:457-458
+        backbone.classifier = nn.Sequential(  # model.py:459-463
+            nn.Linear(feature_width, 1024), nn.Linear(1024, 512), nn.Linear(512, 512),
+            nn.Linear(512, self.num_spaces * self.num_channels * self.num_coeffs))
+        self.backbone = backbone
+        self.rgb2lab, self.lab2rgb = colors.RGB2LAB(), colors.LAB2RGB()
+        self.rgb2hsv, self.hsv2rgb = colors.RGB2HSV(), colors.HSV2RGB()
+        self.sigmoid = nn.Sigmoid()
+
+    def generate_coefficients(self, img, mask):
+        """model.py:522-527."""
+        coeffs = self.backbone(img * mask).reshape(img.shape[0], self.num_spaces, self.num_channels, self.num_coeffs)
+        return coeffs[:, 0], coeffs[:, 1], coeffs[:, 2]
+
+    def generate_residual(self, img, R, L, H):
+        """model.py:499-515, one kernel."""
+        return ops.trispace_forward(img, torch.stack((R, L, H), 1), residual_only=True)
+
+    @staticmethod
+    def generate_image(img, residual):
+        """model.py:517-520."""
+        return torch.clamp(img + residual, 0.0, 1.0)
+
+    def forward(self, img, mask, target_img=None):
+        """model.py:529-535: coefficients from (img*mask); residual on `target_img` (full resolution) if given.
+        is_train=True returns the image clamp(input + residual), else the residual."""
+        coeffs = self.backbone(img * mask).reshape(img.shape[0], self.num_spaces, self.num_channels, self.num_coeffs)
+        input_img = img if target_img is None else target_img
+        return ops.trispace_forward(input_img, coeffs, residual_only=not self.is_train)

@@ -431,12 +431,13 @@ def test_infer_cli_end_to_end(dev, tmp_path):
     Image.fromarray(rgba, "RGBA").save(tmp_path / "in.png")
     Image.fromarray(mask, "L").save(tmp_path / "mask.png")
     torch.manual_seed(0)
-    cli.infer(["--img_path", str(tmp_path / "in.png"), "--mask_path", str(tmp_path / "mask.png"),
-               "--model_file", "random", "--out_path", str(tmp_path / "out.png")])
-    out = np.asarray(Image.open(tmp_path / "out.png"))
-    assert out.shape == (H, W, 3) and out.dtype == np.uint8
-    assert (out[mask == 0] == 255).all()
-    assert out[mask == 255].std() > 0
+    for arch in ("trispace", "curl"):
+        cli.infer(["--img_path", str(tmp_path / "in.png"), "--mask_path", str(tmp_path / "mask.png"),
+                   "--model_file", "random", "--out_path", str(tmp_path / "out.png"), "--arch", arch])
+        out = np.asarray(Image.open(tmp_path / "out.png"))
+        assert out.shape == (H, W, 3) and out.dtype == np.uint8
+        assert (out[mask == 0] == 255).all()
+        assert out[mask == 255].std() > 0
 
 
 # ------------------------------------------------------------------ polynomial path
@@ -478,3 +479,28 @@ def test_trispace_shapes_vs_oracle(ops, dev, shape):
     # the residual spans +-6 here (three spaces x +-2, large coordinate coefficients): same relative error, and
     # the clamped image inherits its ABSOLUTE size
     assert max_err(N(full), O.generate_image(img, ref).numpy()) <= 3e-5
+
+
+def test_trispace_regnet_module(dev):
+    """The mirror of the fork's live model: encoder -> [B,3,3,126] -> fused polynomial kernel, vs the oracle."""
+    import curl_oracle as O
+    from curl_amd import model
+    torch.manual_seed(1)
+    net = model.TriSpaceRegNet(spatial=True, is_train=True, polylayer=model.Deg4MobilePolyLayer(),
+                               backbone=model.CurveEncoder(1, width=0.25, num_features=64), feature_width=64).to(dev).eval()
+    img = torch.rand(2, 3, 48, 80, device=dev)
+    mask = (torch.rand(2, 1, 48, 80, device=dev) > 0.2).float()
+    big = torch.rand(2, 3, 100, 140, device=dev)
+    with torch.no_grad():
+        out = net(img, mask, big)
+        R, L, H = net.generate_coefficients(img, mask)
+        res = net.generate_residual(big, R, L, H)
+    ref = O.trispace_residual(big.cpu(), R.cpu(), L.cpu(), H.cpu())
+    assert max_err(N(res), ref.numpy()) <= 2e-5
+    assert max_err(N(out), O.generate_image(big.cpu(), ref).numpy()) <= 2e-5
+    assert set(k for k in net.state_dict() if k.startswith("backbone.classifier")) >= {
+        "backbone.classifier.0.weight", "backbone.classifier.3.bias"}
+    lay = model.Deg4MobilePolyLayer().to(dev)
+    x5 = torch.rand(2, 5, 16, 16, device=dev)
+    c = torch.randn(2, 3, 126, device=dev) * 0.3
+    assert max_err(N(lay(x5, c)), O.deg4_mobile_poly_layer(x5.cpu(), c.cpu()).numpy()) <= 3e-6
