@@ -48,6 +48,8 @@ SIGNATURES = {
     "curl_poly_layer_f32": (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f]),
     "curl_u8hwc_to_f32chw": (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f]),
     "curl_f32chw_to_u8hwc": (_i, [_c_f, _c_f, _i, _i, _i, _c_f]),
+    "curl_psnr_scratch_bytes": (_sz, [_i, _i, _i]),
+    "curl_psnr_f32": (_i, [_c_f, _c_f, _c_f, _i, _c_f, _c_f, _sz, _i, _i, _i, ctypes.c_float, _c_f]),
     "curl_compose_white_u8hwc": (_i, [_c_f, _c_f, _i, _c_f, _i, _i, _i, _c_f]),
 }
 

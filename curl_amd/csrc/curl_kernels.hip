@@ -727,6 +727,65 @@ __global__ __launch_bounds__(256) void knots_bwd_kernel(KnotsBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// masked PSNR  (metric.py:35-68)
+// ------------------------------------------------------------------------------------------------
+// pass 1: per block, sum over its pixels of (clamp(a)*m - clamp(b)*m)^2 over the 3 channels, and sum of m.
+__global__ __launch_bounds__(256) void psnr_partial_kernel(const float* a, const float* b, const void* mask,
+                                                           int mask_kind, float* partial, unsigned HW,
+                                                           unsigned blocks_per_image) {
+  __shared__ float sS[4], sM[4];
+  const unsigned img = blockIdx.y;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  float se = 0.0f, sm = 0.0f;
+  if (i < HW) {
+    float m = 1.0f;
+    if (mask_kind == CURL_MASK_U8) m = reinterpret_cast<const uint8_t*>(mask)[(size_t)img * HW + i] ? 1.0f : 0.0f;
+    if (mask_kind == CURL_MASK_F32) m = reinterpret_cast<const float*>(mask)[(size_t)img * HW + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      size_t o = ((size_t)img * 3 + c) * HW + i;
+      float d = clamp01(a[o]) * m - clamp01(b[o]) * m;  // metric.py:60-61 then :44
+      se += d * d;
+    }
+    sm = m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    se += __shfl_xor(se, off, 64);
+    sm += __shfl_xor(sm, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) sS[threadIdx.x >> 6] = se, sM[threadIdx.x >> 6] = sm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    size_t r = ((size_t)img * blocks_per_image + blockIdx.x) * 2;
+    partial[r] = (sS[0] + sS[1]) + (sS[2] + sS[3]);
+    partial[r + 1] = (sM[0] + sM[1]) + (sM[2] + sM[3]);
+  }
+}
+// pass 2: one block per image, fixed-order float64 sums -> 10*log10(max^2 / mse), mse = SSE / (3 * sum(mask))
+__global__ __launch_bounds__(256) void psnr_final_kernel(const float* partial, float* out, unsigned blocks_per_image,
+                                                         float max_intensity) {
+  __shared__ double s0[256], s1[256];
+  const float* p = partial + (size_t)blockIdx.x * blocks_per_image * 2;
+  double a = 0.0, b = 0.0;
+  for (unsigned i = threadIdx.x; i < blocks_per_image; i += 256) {
+    a += (double)p[2 * i];
+    b += (double)p[2 * i + 1];
+  }
+  s0[threadIdx.x] = a;
+  s1[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s0[threadIdx.x] += s0[threadIdx.x + off], s1[threadIdx.x] += s1[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double mse = s0[0] / (3.0 * s1[0]);  // metric.py:46-47 (0/0 -> NaN, as in the reference)
+    out[blockIdx.x] = (float)(10.0 * log10((double)max_intensity * (double)max_intensity / mse));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout edges: u8 HWC <-> f32 CHW
 // ------------------------------------------------------------------------------------------------
 // One thread per pixel; HWC bytes of a wave are one contiguous 192/256-byte run, CHW floats three
@@ -1243,6 +1302,31 @@ int curl_compose_white_u8hwc(const float* in, const void* mask, int mask_kind, u
                      (hipStream_t)stream, in, mask, mask_kind, out, HW, total);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "compose_white_u8hwc");
+  return 0;
+}
+
+size_t curl_psnr_scratch_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  size_t blocks = ((size_t)H * W + 255) / 256;
+  return (size_t)B * blocks * 2 * sizeof(float);
+}
+
+int curl_psnr_f32(const float* a, const float* b, const void* mask, int mask_kind, float* psnr, void* scratch,
+                  size_t scratch_bytes, int B, int H, int W, float max_intensity, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(a, b, B, H, W)) return rc;
+  if (!psnr) return fail(CURL_E_NULL, "psnr output is NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  if (!scratch || scratch_bytes < curl_psnr_scratch_bytes(B, H, W))
+    return fail(CURL_E_WORKSPACE, "scratch missing or smaller than curl_psnr_scratch_bytes");
+  unsigned HW = (unsigned)((size_t)H * W), bpi = (HW + 255u) / 256u;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(psnr_partial_kernel, dim3(bpi, (unsigned)B), dim3(256), 0, s, a, b, mask_kind ? mask : nullptr,
+                     mask_kind, (float*)scratch, HW, bpi);
+  hipLaunchKernelGGL(psnr_final_kernel, dim3((unsigned)B), dim3(256), 0, s, (const float*)scratch, psnr, bpi,
+                     max_intensity);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "psnr kernels");
   return 0;
 }
 

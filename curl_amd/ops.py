@@ -311,3 +311,20 @@ def compose_white_u8hwc(x, mask):
     _lib.check(lib.curl_compose_white_u8hwc(x.data_ptr(), m.data_ptr(), kind, out.data_ptr(), B, H, W, _stream(x)),
                "curl_compose_white_u8hwc")
     return out[0] if squeeze else out
+
+
+def psnr_per_image(a, b, mask=None, max_intensity=1.0):
+    """metric.py:35-62 per image: masked PSNR [B] (NaN where an image has no unmasked pixel or zero error -> inf)."""
+    lib = _lib.load()
+    a, b = _image(a, "a"), _image(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("a and b must have the same shape")
+    m, kind = _mask(mask, a)
+    B, _, H, W = a.shape
+    out = torch.empty(B, dtype=torch.float32, device=a.device)
+    nbytes = lib.curl_psnr_scratch_bytes(B, H, W)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+    rc = lib.curl_psnr_f32(a.data_ptr(), b.data_ptr(), _ptr(m), kind, out.data_ptr(), scratch.data_ptr(), nbytes,
+                           B, H, W, float(max_intensity), _stream(a))
+    _lib.check(rc, "curl_psnr_f32")
+    return out

@@ -165,6 +165,15 @@ int curl_f32chw_to_u8hwc(const float* in, uint8_t* out, int B, int H, int W, cur
 int curl_compose_white_u8hwc(const float* in, const void* mask, int mask_kind, uint8_t* out,
                              int B, int H, int W, curl_stream_t stream);
 
+/* replaces: PSNRMetric.compute_psnr  metric.py:35-68 (per-image part)
+ * psnr[b] = 10 log10(max^2 / mse_b), mse_b = sum((clamp(a)*m - clamp(b)*m)^2) / (3 * sum(m)) over image b.
+ * The batch nan-mean of metric.py:66-67 is a [B]-sized host reduction.  mask_kind NONE = all ones.
+ * scratch: curl_psnr_scratch_bytes(B,H,W) bytes; fixed-order float64 reduction (reproducible). */
+size_t curl_psnr_scratch_bytes(int B, int H, int W);
+int curl_psnr_f32(const float* a, const float* b, const void* mask, int mask_kind, float* psnr,
+                  void* scratch, size_t scratch_bytes, int B, int H, int W, float max_intensity,
+                  curl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -504,3 +504,21 @@ def test_trispace_regnet_module(dev):
     x5 = torch.rand(2, 5, 16, 16, device=dev)
     c = torch.randn(2, 3, 126, device=dev) * 0.3
     assert max_err(N(lay(x5, c)), O.deg4_mobile_poly_layer(x5.cpu(), c.cpu()).numpy()) <= 3e-6
+
+
+def test_psnr_golden_and_oracle(dev, golden):
+    """Masked PSNR (metric.py:35-68) vs the value the reference's PSNRMetric produced, and per image vs the oracle."""
+    import curl_oracle as O
+    from curl_amd import metric, ops as _ops
+    c = golden("chain")
+    a, b, m = T(c["psnr_a"], dev), T(c["psnr_b"], dev), T(c["mask_disk"], dev)
+    for mm in (m, m.float()):
+        v = metric.PSNRMetric()(a, b, mm)
+        assert abs(float(v) - float(c["psnr_val"])) < 1e-4
+    per = _ops.psnr_per_image(a, b, m)
+    for i in range(a.shape[0]):
+        want = O.psnr(torch.from_numpy(c["psnr_a"][i:i + 1]), torch.from_numpy(c["psnr_b"][i:i + 1]),
+                      torch.from_numpy(c["mask_disk"][i:i + 1].astype(np.float32)))
+        assert abs(float(per[i]) - float(want)) < 1e-4
+    empty = torch.zeros_like(m)
+    assert metric.PSNRMetric()(a, b, empty) is None  # 0/0 -> NaN for every image -> None (metric.py:67-68)
