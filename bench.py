@@ -102,7 +102,8 @@ def timed_run(step, sets, steps, warmup, dist, device):
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / steps
     if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
+        on = device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
     return wall, dev_ms
@@ -196,13 +197,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: this path has no CPU fallback")
-    device = torch.device("cuda", local)
+    # one rank per GPU; (a rehearsal with more ranks than GPUs -- CURL_DIST_BACKEND=gloo on a 1-GPU box -- wraps)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("CURL_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
