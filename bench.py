@@ -231,7 +231,8 @@ def main():
         return {
             "workload": desc, "value": mpix, "ms_per_step": wall / steps * 1e3, "device_ms_per_step": dev_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(frag),
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": load_traffic(frag) if B == 32 else None,  # PMC pass was taken at bs32
                          "algorithmic_bytes_per_px": bpp, "px_per_launch": npx_rank,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
