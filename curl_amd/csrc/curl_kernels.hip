@@ -18,6 +18,7 @@
 #include "../../include/curl_hip.h"
 #include "curl_math_bwd.h"
 #include "curl_math_poly.h"
+#include "curl_math_loss.h"
 
 using namespace curlm;
 
@@ -786,6 +787,76 @@ __global__ __launch_bounds__(256) void psnr_final_kernel(const float* partial, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// CURLLoss pointwise terms (model.py:78-116)
+// ------------------------------------------------------------------------------------------------
+#define LOSS_NSUM 5  // sum|p-t|, sum cos, sum|lab|, sum|cone|, sum mask
+__device__ __forceinline__ float load_mask(const void* mask, int mask_kind, size_t i) {
+  if (mask_kind == CURL_MASK_U8) return reinterpret_cast<const uint8_t*>(mask)[i] ? 1.0f : 0.0f;
+  if (mask_kind == CURL_MASK_F32) return reinterpret_cast<const float*>(mask)[i];
+  return 1.0f;
+}
+__global__ __launch_bounds__(256) void loss_terms_kernel(const float* pred, const float* tgt, const void* mask,
+                                                         int mask_kind, float* partial, float* Lp, float* Lt,
+                                                         unsigned HW, unsigned blocks_per_image) {
+  __shared__ float sP[4][LOSS_NSUM];
+  const unsigned img = blockIdx.y;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  float acc[LOSS_NSUM] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (i < HW) {
+    size_t o = (size_t)img * 3 * HW + i, mo = (size_t)img * HW + i;
+    float m = load_mask(mask, mask_kind, mo);
+    LossPx r = loss_terms(Px{pred[o], pred[o + HW], pred[o + 2 * (size_t)HW]},
+                          Px{tgt[o], tgt[o + HW], tgt[o + 2 * (size_t)HW]}, m);
+    acc[0] = r.rgb_l1, acc[1] = r.cos_sim, acc[2] = r.lab_l1, acc[3] = r.hsv_l1, acc[4] = m;
+    if (Lp) Lp[mo] = r.Lp;
+    if (Lt) Lt[mo] = r.Lt;
+  }
+#pragma unroll
+  for (int c = 0; c < LOSS_NSUM; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sP[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < LOSS_NSUM) {
+    int c = threadIdx.x;
+    partial[((size_t)img * blocks_per_image + blockIdx.x) * LOSS_NSUM + c] = (sP[0][c] + sP[1][c]) + (sP[2][c] + sP[3][c]);
+  }
+}
+__global__ __launch_bounds__(256) void loss_terms_final_kernel(const float* partial, double* sums, unsigned blocks_per_image) {
+  __shared__ double sA[256];
+  const float* p = partial + (size_t)blockIdx.x * blocks_per_image * LOSS_NSUM;
+  for (int c = 0; c < LOSS_NSUM; ++c) {
+    double v = 0.0;
+    for (unsigned i = threadIdx.x; i < blocks_per_image; i += 256) v += (double)p[(size_t)i * LOSS_NSUM + c];
+    sA[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sA[threadIdx.x] += sA[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[(size_t)blockIdx.x * LOSS_NSUM + c] = sA[0];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void loss_terms_bwd_kernel(const float* pred, const float* tgt, const void* mask,
+                                                             int mask_kind, const float* w4, const float* gLp,
+                                                             float* gpred, unsigned HW) {
+  const unsigned img = blockIdx.y;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= HW) return;
+  size_t o = (size_t)img * 3 * HW + i, mo = (size_t)img * HW + i;
+  const float w[4] = {w4[0], w4[1], w4[2], w4[3]};
+  Px g = loss_terms_bwd(Px{pred[o], pred[o + HW], pred[o + 2 * (size_t)HW]},
+                        Px{tgt[o], tgt[o + HW], tgt[o + 2 * (size_t)HW]}, load_mask(mask, mask_kind, mo), w,
+                        gLp ? gLp[mo] : 0.0f);
+  gpred[o] = g.c0;
+  gpred[o + HW] = g.c1;
+  gpred[o + 2 * (size_t)HW] = g.c2;
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout edges: u8 HWC <-> f32 CHW
 // ------------------------------------------------------------------------------------------------
 // One thread per pixel; HWC bytes of a wave are one contiguous 192/256-byte run, CHW floats three
@@ -1327,6 +1398,45 @@ int curl_psnr_f32(const float* a, const float* b, const void* mask, int mask_kin
                      max_intensity);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "psnr kernels");
+  return 0;
+}
+
+size_t curl_loss_terms_scratch_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * (((size_t)H * W + 255) / 256) * LOSS_NSUM * sizeof(float);
+}
+
+int curl_loss_terms_f32(const float* pred, const float* target, const void* mask, int mask_kind, double* sums,
+                        float* L_pred, float* L_target, void* scratch, size_t scratch_bytes, int B, int H, int W,
+                        curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(pred, target, B, H, W)) return rc;
+  if (!sums) return fail(CURL_E_NULL, "sums is NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  if (!scratch || scratch_bytes < curl_loss_terms_scratch_bytes(B, H, W))
+    return fail(CURL_E_WORKSPACE, "scratch missing or smaller than curl_loss_terms_scratch_bytes");
+  unsigned HW = (unsigned)((size_t)H * W), bpi = (HW + 255u) / 256u;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_terms_kernel, dim3(bpi, (unsigned)B), dim3(256), 0, s, pred, target,
+                     mask_kind ? mask : nullptr, mask_kind, (float*)scratch, L_pred, L_target, HW, bpi);
+  hipLaunchKernelGGL(loss_terms_final_kernel, dim3((unsigned)B), dim3(256), 0, s, (const float*)scratch, sums, bpi);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "loss_terms kernels");
+  return 0;
+}
+
+int curl_loss_terms_bwd_f32(const float* pred, const float* target, const void* mask, int mask_kind,
+                            const float* weights, const float* grad_L_pred, float* grad_pred, int B, int H, int W,
+                            curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(pred, target, B, H, W)) return rc;
+  if (!weights || !grad_pred) return fail(CURL_E_NULL, "weights / grad_pred is NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  unsigned HW = (unsigned)((size_t)H * W), bpi = (HW + 255u) / 256u;
+  hipLaunchKernelGGL(loss_terms_bwd_kernel, dim3(bpi, (unsigned)B), dim3(256), 0, (hipStream_t)stream, pred, target,
+                     mask_kind ? mask : nullptr, mask_kind, weights, grad_L_pred, grad_pred, HW);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "loss_terms_bwd_kernel");
   return 0;
 }
 

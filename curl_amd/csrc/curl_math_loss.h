@@ -1,0 +1,76 @@
+// curl_math_loss.h -- the per-pixel terms of the reference's CURLLoss (model.py:78-116):
+// masked L1 in RGB, cosine similarity, L1 in clamped Lab, L1 on the HSV cone.  (The MS-SSIM term of
+// model.py:103-105 is grouped convolutions on the L plane -- stock PyTorch; this header hands it the L planes
+// and takes its gradient back.)  Same dual compilation as curl_math.h.
+#pragma once
+#include "curl_math_bwd.h"
+
+namespace curlm {
+
+constexpr float kTwoPi = (float)(2 * 3.141592653589793);  // 2*math.pi as float32 (model.py:70)
+constexpr float kCosEps = 1e-8f;                          // torch cosine_similarity eps
+
+struct LossPx {
+  float rgb_l1, cos_sim, lab_l1, hsv_l1;  // this pixel's contribution to the four sums
+  float Lp, Lt;                           // clamped L of prediction and target (for MS-SSIM)
+};
+
+CURL_HD Px hsv_cone(Px hsv) {  // model.py:65-76 on clamp(rgb2hsv(x), 0, 1)
+  float h = clamp01(hsv.c0), s = clamp01(hsv.c1), v = clamp01(hsv.c2);
+  float a = kTwoPi * h;
+  return Px{v * s * cosf(a), v * s * sinf(a), v};
+}
+
+CURL_HD LossPx loss_terms(Px pred, Px tgt, float m) {
+  Px p{pred.c0 * m, pred.c1 * m, pred.c2 * m}, t{tgt.c0 * m, tgt.c1 * m, tgt.c2 * m};  // model.py:91
+  LossPx o;
+  o.rgb_l1 = (fabsf(p.c0 - t.c0) + fabsf(p.c1 - t.c1)) + fabsf(p.c2 - t.c2);  // model.py:93
+  float d = p.c0 * t.c0 + p.c1 * t.c1 + p.c2 * t.c2;
+  float np = sqrtf(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = sqrtf(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
+  o.cos_sim = d / (fmaxf(np, kCosEps) * fmaxf(nt, kCosEps));  // model.py:97
+  Px lp = rgb2lab(p), lt = rgb2lab(t);                          // model.py:100-101 (+ clamp, model.py:55)
+  lp = Px{clamp01(lp.c0), clamp01(lp.c1), clamp01(lp.c2)};
+  lt = Px{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
+  o.lab_l1 = (fabsf(lp.c0 - lt.c0) + fabsf(lp.c1 - lt.c1)) + fabsf(lp.c2 - lt.c2);
+  o.Lp = lp.c0;
+  o.Lt = lt.c0;
+  Px cp = hsv_cone(rgb2hsv(p)), ct = hsv_cone(rgb2hsv(t));      // model.py:107-109
+  o.hsv_l1 = (fabsf(cp.c0 - ct.c0) + fabsf(cp.c1 - ct.c1)) + fabsf(cp.c2 - ct.c2);
+  return o;
+}
+
+CURL_HD float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }  // torch.sign / l1 backward
+
+// d(sum_k w[k] * term_k + gLp * Lp) / d pred for one pixel; w = weights of (rgb_l1, cos_sim, lab_l1, hsv_l1).
+CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float gLp) {
+  Px p{pred.c0 * m, pred.c1 * m, pred.c2 * m}, t{tgt.c0 * m, tgt.c1 * m, tgt.c2 * m};
+  // rgb L1
+  Px g{w[0] * sign0(p.c0 - t.c0), w[0] * sign0(p.c1 - t.c1), w[0] * sign0(p.c2 - t.c2)};
+  // cosine similarity: c = d / (max(np,eps) max(nt,eps))
+  float d = p.c0 * t.c0 + p.c1 * t.c1 + p.c2 * t.c2;
+  float np = sqrtf(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = sqrtf(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
+  float npc = fmaxf(np, kCosEps), ntc = fmaxf(nt, kCosEps);
+  float inv = 1.0f / (npc * ntc);
+  float k = (np > kCosEps) ? d * inv / (npc * np) : 0.0f;  // d/dp of 1/max(np,eps) is -p/np^3-ish only when np > eps
+  g.c0 += w[1] * (t.c0 * inv - k * p.c0);
+  g.c1 += w[1] * (t.c1 * inv - k * p.c1);
+  g.c2 += w[1] * (t.c2 * inv - k * p.c2);
+  // Lab L1 (+ the MS-SSIM gradient arriving on the clamped L plane)
+  Px lp = rgb2lab(p), lt = rgb2lab(t);
+  Px lpc{clamp01(lp.c0), clamp01(lp.c1), clamp01(lp.c2)}, ltc{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
+  Px gl{(w[2] * sign0(lpc.c0 - ltc.c0) + gLp) * pass01(lp.c0), w[2] * sign0(lpc.c1 - ltc.c1) * pass01(lp.c1),
+        w[2] * sign0(lpc.c2 - ltc.c2) * pass01(lp.c2)};
+  Px g_lab = rgb2lab_bwd(p, gl);
+  // HSV cone L1
+  Px hp = rgb2hsv(p);
+  Px cp = hsv_cone(hp), ct = hsv_cone(rgb2hsv(t));
+  float ge0 = w[3] * sign0(cp.c0 - ct.c0), ge1 = w[3] * sign0(cp.c1 - ct.c1), ge2 = w[3] * sign0(cp.c2 - ct.c2);
+  float h = clamp01(hp.c0), s = clamp01(hp.c1), v = clamp01(hp.c2);
+  float a = kTwoPi * h, ca = cosf(a), sa = sinf(a);
+  Px gh{kTwoPi * v * s * (ge1 * ca - ge0 * sa) * pass01(hp.c0), v * (ge0 * ca + ge1 * sa) * pass01(hp.c1),
+        (s * (ge0 * ca + ge1 * sa) + ge2) * pass01(hp.c2)};
+  Px g_hsv = rgb2hsv_bwd(p, gh);
+  return Px{(g.c0 + g_lab.c0 + g_hsv.c0) * m, (g.c1 + g_lab.c1 + g_hsv.c1) * m, (g.c2 + g_lab.c2 + g_hsv.c2) * m};
+}
+
+}  // namespace curlm

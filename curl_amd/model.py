@@ -275,3 +275,50 @@ class TriSpaceRegNet(nn.Module):
         coeffs = self.backbone(img * mask).reshape(img.shape[0], self.num_spaces, self.num_channels, self.num_coeffs)
         input_img = img if target_img is None else target_img
         return ops.trispace_forward(input_img, coeffs, residual_only=not self.is_train)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CURLLoss (model.py:35-118): the four per-pixel terms in one fused HIP pass (+ backward); MS-SSIM is injected.
+# ---------------------------------------------------------------------------------------------------------
+class _LossTermsFn(torch.autograd.Function):
+    """(pred, target, mask) -> (rgb_l1, cosine, lab_l1, hsv_l1, L_pred, L_target) as in model.py:89-109."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        sums, Lp, Lt = ops.loss_term_sums(pred, target, mask)
+        s = sums.sum(0)
+        n = float(pred.shape[0] * pred.shape[2] * pred.shape[3])
+        unmasked = 3.0 * s[4]
+        rgb, lab, hsv = s[0] / unmasked, s[2] / unmasked, s[3] / unmasked
+        cosine = 1.0 - s[1] / n - (n - s[4]) / n  # model.py:98: mean over the broadcast [B,B,H,W]
+        ctx.save_for_backward(pred, target, unmasked)
+        ctx.mask, ctx.n = mask, n
+        ctx.mark_non_differentiable(Lt)
+        f = torch.float32
+        return rgb.to(f), cosine.to(f), lab.to(f), hsv.to(f), Lp, Lt
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_cos, g_lab, g_hsv, g_Lp, _g_Lt):
+        pred, target, unmasked = ctx.saved_tensors
+        w = torch.stack((g_rgb.double() / unmasked, -g_cos.double() / ctx.n, g_lab.double() / unmasked,
+                         g_hsv.double() / unmasked)).to(torch.float32)
+        return ops.loss_terms_backward(pred, target, ctx.mask, w, g_Lp), None, None
+
+
+class CURLLoss(nn.Module):
+    """model.py:35-118.  `msssim_layer(L_pred, L_target)` supplies the MS-SSIM of model.py:103-105 (the
+    reference's MSSSIMMetric is grouped convolutions, metric.py:75-211; it is not rebuilt here and its
+    constructor cannot run without a GPU, so that term is parity-unpinned); None leaves the term at zero."""
+
+    def __init__(self, ssim_window_size=5, num_channel=1, msssim_layer=None):
+        super().__init__()
+        self.ssim_window_size = ssim_window_size
+        self.num_channel = num_channel
+        self.msssim_layer = msssim_layer
+        self.rgb2lab = colors.RGB2LAB()
+        self.rgb2hsv = colors.RGB2HSV()
+
+    def forward(self, predicted_img_batch, target_img_batch, mask):
+        rgb, cosine, lab, hsv, Lp, Lt = _LossTermsFn.apply(predicted_img_batch, target_img_batch, mask)
+        ssim = (1.0 - self.msssim_layer(Lp, Lt)).mean() if self.msssim_layer is not None else 0.0
+        return (rgb + cosine + lab + hsv + 10 * ssim) / 5  # model.py:111-116

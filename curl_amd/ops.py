@@ -328,3 +328,38 @@ def psnr_per_image(a, b, mask=None, max_intensity=1.0):
                            B, H, W, float(max_intensity), _stream(a))
     _lib.check(rc, "curl_psnr_f32")
     return out
+
+
+def loss_term_sums(pred, target, mask, want_L=True):
+    """Per-image sums of the CURLLoss pointwise terms (model.py:89-109): [B,5] float64 =
+    (sum|p-t|, sum cos_sim, sum|lab|, sum|hsv cone|, sum mask), plus the clamped L planes for MS-SSIM."""
+    lib = _lib.load()
+    pred, target = _image(pred, "pred"), _image(target, "target")
+    if pred.shape != target.shape:
+        raise ValueError("pred and target must have the same shape")
+    m, kind = _mask(mask, pred)
+    B, _, H, W = pred.shape
+    sums = torch.empty(B, 5, dtype=torch.float64, device=pred.device)
+    Lp = torch.empty(B, 1, H, W, dtype=torch.float32, device=pred.device) if want_L else None
+    Lt = torch.empty_like(Lp) if want_L else None
+    nbytes = lib.curl_loss_terms_scratch_bytes(B, H, W)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=pred.device)
+    rc = lib.curl_loss_terms_f32(pred.data_ptr(), target.data_ptr(), _ptr(m), kind, sums.data_ptr(), _ptr(Lp), _ptr(Lt),
+                                 scratch.data_ptr(), nbytes, B, H, W, _stream(pred))
+    _lib.check(rc, "curl_loss_terms_f32")
+    return sums, Lp, Lt
+
+
+def loss_terms_backward(pred, target, mask, weights, grad_L_pred=None):
+    """d(sum_k weights[k] * sum_k-th pointwise sum + <grad_L_pred, L_pred>) / d pred.  weights: device float32 [4]."""
+    lib = _lib.load()
+    pred, target = _image(pred, "pred"), _image(target, "target")
+    m, kind = _mask(mask, pred)
+    B, _, H, W = pred.shape
+    w = weights.to(torch.float32).contiguous()
+    g = None if grad_L_pred is None else grad_L_pred.to(torch.float32).contiguous()
+    out = torch.empty_like(pred)
+    rc = lib.curl_loss_terms_bwd_f32(pred.data_ptr(), target.data_ptr(), _ptr(m), kind, w.data_ptr(), _ptr(g),
+                                     out.data_ptr(), B, H, W, _stream(pred))
+    _lib.check(rc, "curl_loss_terms_bwd_f32")
+    return out

@@ -174,6 +174,23 @@ int curl_psnr_f32(const float* a, const float* b, const void* mask, int mask_kin
                   void* scratch, size_t scratch_bytes, int B, int H, int W, float max_intensity,
                   curl_stream_t stream);
 
+/* replaces: the per-pixel terms of CURLLoss.forward  model.py:89-109 (masked L1 in RGB, cosine similarity,
+ *           L1 in clamped Lab, L1 on the HSV cone) in one pass over prediction and target.
+ * sums [B,5] float64 (ASSIGNED), per image: sum|p-t|, sum cos_sim, sum|lab_p-lab_t|, sum|cone_p-cone_t|, sum(mask).
+ * The caller forms model.py:93-109 from them: unmasked = 3*sum(mask) over the batch;
+ * cosine term = 1 - mean(cos) - mean(not mask) (what model.py:98's broadcast [B,B,H,W] mean evaluates to).
+ * L_pred / L_target [B,1,H,W] (nullable): clamped L planes for the MS-SSIM term (model.py:103-105), which stays
+ * stock PyTorch.  scratch: curl_loss_terms_scratch_bytes(B,H,W). */
+size_t curl_loss_terms_scratch_bytes(int B, int H, int W);
+int curl_loss_terms_f32(const float* pred, const float* target, const void* mask, int mask_kind, double* sums,
+                        float* L_pred, float* L_target, void* scratch, size_t scratch_bytes,
+                        int B, int H, int W, curl_stream_t stream);
+/* Backward of the above w.r.t. pred.  weights: DEVICE pointer to 4 floats = d loss / d (each of the four sums);
+ * grad_L_pred [B,1,H,W] (nullable): d loss / d L_pred from the MS-SSIM branch.  grad_pred [B,3,H,W] ASSIGNED. */
+int curl_loss_terms_bwd_f32(const float* pred, const float* target, const void* mask, int mask_kind,
+                            const float* weights, const float* grad_L_pred, float* grad_pred,
+                            int B, int H, int W, curl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -409,3 +409,36 @@ def trispace_residual(img, R, L, H, spatial=True, mobile=True):
 def generate_image(img, residual):
     """TriSpaceRegNet.generate_image (model.py:517-520)."""
     return torch.clamp(img + residual, 0.0, 1.0)
+
+
+# ---------------------------------------------------------------------------
+# model.py:78-116 : the per-pixel terms of CURLLoss (SURVEY.md 8f-3)
+# ---------------------------------------------------------------------------
+def _hsv_cone(img):
+    """CURLLoss.batch_hsv_convert (model.py:62-76)."""
+    hsv = torch.clamp(rgb2hsv(img), 0.0, 1.0)
+    hue = 2 * math.pi * hsv[:, 0]
+    val, sat = hsv[:, 2], hsv[:, 1]
+    return torch.stack((val * sat * torch.cos(hue), val * sat * torch.sin(hue), val), 1)
+
+
+def curl_loss_terms(pred, target, mask):
+    """CURLLoss.forward (model.py:89-109) without the MS-SSIM term: returns
+    (rgb_loss, cosine_rgb_loss, lab_l1_loss, hsv_loss, L_pred, L_target)."""
+    import torch.nn.functional as F
+    unmasked = pred.shape[1] * mask.sum()
+    p, t = pred * mask, target * mask
+    rgb = F.l1_loss(p, t, reduction='sum') / unmasked
+    base = F.cosine_similarity(p, t, dim=1)
+    cosine = (1.0 - (base + torch.logical_not(mask)).mean(dim=(1, 2))).mean()
+    lab_t = torch.clamp(rgb2lab(t), 0.0, 1.0)
+    lab_p = torch.clamp(rgb2lab(p), 0.0, 1.0)
+    lab = F.l1_loss(lab_p, lab_t, reduction='sum') / unmasked
+    hsv = F.l1_loss(_hsv_cone(p), _hsv_cone(t), reduction='sum') / unmasked
+    return rgb, cosine, lab, hsv, lab_p[:, 0:1], lab_t[:, 0:1]
+
+
+def curl_loss(pred, target, mask, ssim_loss_value):
+    """model.py:111-116 given the MS-SSIM loss term."""
+    rgb, cosine, lab, hsv, _, _ = curl_loss_terms(pred, target, mask)
+    return (rgb + cosine + lab + hsv + 10 * ssim_loss_value) / 5

@@ -52,10 +52,11 @@ def twin():
     hdr = os.path.join(ROOT, "curl_amd", "csrc", "curl_math.h")
     hdr2 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_bwd.h")
     hdr3 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_poly.h")
+    hdr4 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_loss.h")
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libcurl_twin.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2), os.path.getmtime(hdr3)):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2), os.path.getmtime(hdr3), os.path.getmtime(hdr4)):
         subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
                                "-DCURL_HOST_TWIN", "-Wno-unknown-pragmas", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -132,6 +133,24 @@ def twin():
             out = np.empty((B, 3, Hh, W), np.float32)
             lib.twin_poly_layer(P(img), P(coeffs), P(out), B, ctypes.c_long(Hh * W), V)
             return out
+
+        @staticmethod
+        def loss_terms(pred, tgt, mask):
+            pred, tgt, mask = f32(pred), f32(tgt), f32(mask)
+            B, _, Hh, W = pred.shape
+            sums = np.zeros((B, 5), np.float64)
+            Lp, Lt = np.empty((B, 1, Hh, W), np.float32), np.empty((B, 1, Hh, W), np.float32)
+            lib.twin_loss_terms(P(pred), P(tgt), P(mask), sums.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), P(Lp), P(Lt),
+                                B, ctypes.c_long(Hh * W))
+            return sums, Lp, Lt
+
+        @staticmethod
+        def loss_terms_bwd(pred, tgt, mask, w4, gLp):
+            pred, tgt, mask, w4, gLp = f32(pred), f32(tgt), f32(mask), f32(w4), f32(gLp)
+            B, _, Hh, W = pred.shape
+            g = np.empty_like(pred)
+            lib.twin_loss_terms_bwd(P(pred), P(tgt), P(mask), P(w4), P(gLp), P(g), B, ctypes.c_long(Hh * W))
+            return g
 
     return Twin
 

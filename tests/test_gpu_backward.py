@@ -111,3 +111,46 @@ def test_train_step_gcurlnet(dev):
         opt.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses))
+
+
+def test_curl_loss_terms_golden(dev, golden):
+    """CURLLoss pointwise terms + gradient (model.py:89-109) vs values computed with the reference's colors.py."""
+    from curl_amd import model
+    g = golden("loss")
+    tgt = T(g["target"], dev)
+    wl = T(g["wl"], dev)
+    w = g["weights"]
+    for mk, m in (("bool", T(g["mask"], dev)), ("f32", T(g["mask"], dev).float())):
+        pred = T(g["pred"], dev).requires_grad_(True)
+        rgb, cosv, lab, hsv, Lp, Lt = model._LossTermsFn.apply(pred, tgt, m)
+        for name, v in (("rgb", rgb), ("cos", cosv), ("lab", lab), ("hsv", hsv)):
+            assert abs(float(v) - float(g[f"{mk}_{name}"])) <= 3e-6, (mk, name)
+        assert (Lp.detach().cpu().numpy() - g[f"{mk}_Lp"]).__abs__().max() <= 1e-6
+        assert (Lt.cpu().numpy() - g[f"{mk}_Lt"]).__abs__().max() <= 1e-6
+        total = float(w[0]) * rgb + float(w[1]) * cosv + float(w[2]) * lab + float(w[3]) * hsv + (Lp * wl).sum() * 1e-3
+        total.backward()
+        ref = g[f"{mk}_grad_pred"]
+        d = np.abs(pred.grad.cpu().numpy() - ref)
+        assert np.quantile(d, 0.995) <= 2e-4 * np.abs(ref).max() and d.max() <= 5e-2 * np.abs(ref).max()
+
+
+def test_curl_loss_module_vs_oracle(dev):
+    import curl_oracle as O
+    from curl_amd import model
+    g = torch.Generator().manual_seed(8)
+    pred, tgt = torch.rand(3, 3, 40, 56, generator=g), torch.rand(3, 3, 40, 56, generator=g)
+    mask = torch.rand(3, 1, 40, 56, generator=g) > 0.3
+    want = O.curl_loss(pred, tgt, mask, torch.tensor(0.0))
+    got = model.CURLLoss()(pred.to(dev), tgt.to(dev), mask.to(dev))
+    assert abs(float(got) - float(want)) <= 2e-6
+    fake_ssim = lambda a, b: 1.0 - (a - b).abs().mean(dim=(1, 2, 3))  # noqa: E731  (stands in for MS-SSIM)
+    p = pred.to(dev).requires_grad_(True)
+    loss = model.CURLLoss(msssim_layer=fake_ssim)(p, tgt.to(dev), mask.to(dev))
+    loss.backward()
+    pc = pred.clone().requires_grad_(True)
+    r = O.curl_loss_terms(pc, tgt, mask)
+    ref = (r[0] + r[1] + r[2] + r[3] + 10 * (1.0 - fake_ssim(r[4], r[5])).mean()) / 5
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6
+    d = (p.grad.cpu() - pc.grad).abs()
+    assert float(torch.quantile(d.flatten(), 0.995)) <= 2e-4 * float(pc.grad.abs().max())

@@ -1,0 +1,53 @@
+"""CURLLoss pointwise terms (model.py:78-116): oracle and kernel arithmetic (host twin) vs golden values computed
+with the reference's colors.py and torch autograd."""
+import numpy as np
+import torch
+
+import curl_oracle as O
+
+
+def terms_from_sums(sums, n_px_total):
+    """Assemble the four loss terms of model.py:89-109 from per-image sums [B,5]."""
+    s = sums.sum(0)
+    unmasked = 3.0 * s[4]
+    rgb, lab, hsv = s[0] / unmasked, s[2] / unmasked, s[3] / unmasked
+    # (base + not mask).mean over the broadcast [B,B,H,W] == mean(base) + mean(not mask)
+    cosine = 1.0 - s[1] / n_px_total - (n_px_total - s[4]) / n_px_total
+    return rgb, cosine, lab, hsv
+
+
+def test_oracle_matches_golden(golden):
+    g = golden("loss")
+    pred, tgt = torch.from_numpy(g["pred"]), torch.from_numpy(g["target"])
+    for mk, m in (("bool", torch.from_numpy(g["mask"])), ("f32", torch.from_numpy(g["mask"]).float())):
+        rgb, cosv, lab, hsv, Lp, Lt = O.curl_loss_terms(pred, tgt, m)
+        for name, v in (("rgb", rgb), ("cos", cosv), ("lab", lab), ("hsv", hsv)):
+            assert abs(float(v) - float(g[f"{mk}_{name}"])) <= 2e-7 * max(1.0, abs(float(v))), name
+        assert np.abs(Lp.numpy() - g[f"{mk}_Lp"]).max() <= 2e-7
+
+
+def test_twin_terms(twin, golden):
+    g = golden("loss")
+    m = g["mask"].astype(np.float32)
+    sums, Lp, Lt = twin.loss_terms(g["pred"], g["target"], m)
+    B, _, H, W = g["pred"].shape
+    rgb, cosine, lab, hsv = terms_from_sums(sums, B * H * W)
+    for name, v in (("rgb", rgb), ("cos", cosine), ("lab", lab), ("hsv", hsv)):
+        assert abs(v - float(g[f"bool_{name}"])) <= 2e-6, (name, v, float(g[f"bool_{name}"]))
+    assert np.abs(Lp - g["bool_Lp"]).max() <= 1e-6 and np.abs(Lt - g["bool_Lt"]).max() <= 1e-6
+
+
+def test_twin_backward(twin, golden):
+    """loss = 1.3 rgb + 0.7 cosine + 2.0 lab + 0.5 hsv + 1e-3 sum(Lp * wl): d/d pred vs autograd."""
+    g = golden("loss")
+    m = g["mask"].astype(np.float32)
+    B, _, H, W = g["pred"].shape
+    n, unmasked = B * H * W, 3.0 * m.sum()
+    w = g["weights"]
+    # weights of the per-pixel SUMS: d term / d sum
+    w4 = np.array([w[0] / unmasked, -w[1] / n, w[2] / unmasked, w[3] / unmasked], np.float32)
+    got = twin.loss_terms_bwd(g["pred"], g["target"], m, w4, g["wl"] * 1e-3)
+    ref = g["bool_grad_pred"]
+    d = np.abs(got - ref)
+    scale = np.abs(ref).max()
+    assert np.quantile(d, 0.995) <= 2e-4 * scale and d.max() <= 5e-2 * scale

@@ -11,6 +11,7 @@
 
 #include "../../curl_amd/csrc/curl_math_bwd.h"
 #include "../../curl_amd/csrc/curl_math_poly.h"
+#include "../../curl_amd/csrc/curl_math_loss.h"
 
 using namespace curlm;
 
@@ -202,6 +203,39 @@ int twin_poly_layer(const float* img, const float* coeffs, float* out, int B, lo
         poly3_n<3, 1>(o, v, coeffs + (size_t)b * 3 * NC);
       }
       for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + i] = o[c][0];
+    }
+  return 0;
+}
+
+// CURLLoss pointwise terms: sums [B][5] = (sum|p-t|, sum cos, sum|lab|, sum|cone|, sum mask); L planes optional.
+int twin_loss_terms(const float* pred, const float* tgt, const float* mask, double* sums, float* Lp, float* Lt, int B,
+                    long HW) {
+  for (int b = 0; b < B; ++b) {
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (long i = 0; i < HW; ++i) {
+      const float* p = pred + (size_t)b * 3 * HW + i;
+      const float* t = tgt + (size_t)b * 3 * HW + i;
+      float m = mask ? mask[(size_t)b * HW + i] : 1.0f;
+      LossPx o = loss_terms(Px{p[0], p[HW], p[2 * HW]}, Px{t[0], t[HW], t[2 * HW]}, m);
+      acc[0] += o.rgb_l1, acc[1] += o.cos_sim, acc[2] += o.lab_l1, acc[3] += o.hsv_l1, acc[4] += m;
+      if (Lp) Lp[(size_t)b * HW + i] = o.Lp;
+      if (Lt) Lt[(size_t)b * HW + i] = o.Lt;
+    }
+    for (int k = 0; k < 5; ++k) sums[b * 5 + k] = acc[k];
+  }
+  return 0;
+}
+int twin_loss_terms_bwd(const float* pred, const float* tgt, const float* mask, const float* w4, const float* gLp,
+                        float* gpred, int B, long HW) {
+  const float w[4] = {w4[0], w4[1], w4[2], w4[3]};
+  for (int b = 0; b < B; ++b)
+    for (long i = 0; i < HW; ++i) {
+      const float* p = pred + (size_t)b * 3 * HW + i;
+      const float* t = tgt + (size_t)b * 3 * HW + i;
+      float m = mask ? mask[(size_t)b * HW + i] : 1.0f;
+      Px g = loss_terms_bwd(Px{p[0], p[HW], p[2 * HW]}, Px{t[0], t[HW], t[2 * HW]}, m, w, gLp ? gLp[(size_t)b * HW + i] : 0.0f);
+      float* q = gpred + (size_t)b * 3 * HW + i;
+      q[0] = g.c0, q[HW] = g.c1, q[2 * HW] = g.c2;
     }
   return 0;
 }
