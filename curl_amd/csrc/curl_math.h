@@ -104,7 +104,7 @@ constexpr float kEps3 = (float)(kEpsD * kEpsD * kEpsD);
 constexpr float k3Eps2 = (float)(3.0 * kEpsD * kEpsD);
 constexpr float kInv3Eps2 = (float)(1.0 / (3.0 * kEpsD * kEpsD));
 constexpr float k4_29 = (float)(4.0 / 29.0);
-constexpr float kFloor = (float)0.0001;  // clamp(min=0.0001) in front of every pow
+// (the reference's clamp(min=0.0001) in front of every pow guards only the branch its select discards: dropped)
 // colors.py:24,41 : XYZ is multiplied by the float32 reciprocals of the D65 white point
 constexpr float kInvXn = 1.0f / 0.950456f;
 constexpr float kInvZn = 1.0f / 1.088754f;
@@ -291,12 +291,6 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 }
 
 // ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
-CURL_HD float lab_finv(float f) {
-  // colors.py:110-111 ; x**3.0 is x*x*x in torch (cube taken only for f > eps > 1e-4)
-  float lin = fmaf(f, k3Eps2, -(k3Eps2 * k4_29));
-  float cub = f * f * f;
-  return select_le(f, kEps, lin, cub);
-}
 template <int N>
 CURL_HD void lab2rgb_n(PxN<N>& p) {
   float X[3 * N], v[3 * N], g[3 * N], lin[3 * N];
