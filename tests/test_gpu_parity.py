@@ -522,3 +522,25 @@ def test_psnr_golden_and_oracle(dev, golden):
         assert abs(float(per[i]) - float(want)) < 1e-4
     empty = torch.zeros_like(m)
     assert metric.PSNRMetric()(a, b, empty) is None  # 0/0 -> NaN for every image -> None (metric.py:67-68)
+
+
+def test_hip_graph_capture_and_replay(ops, dev, golden):
+    """The C ABI never allocates or synchronises, so a whole step (knot prep + fused layer) captures into a
+    hipGraph and replays on new data in the same buffers."""
+    c = golden("chain")
+    L, R, H = (T(c["s01" + k], dev) for k in ("_L", "_R", "_H"))
+    static_in = T(c["img"], dev).clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):  # warm-up outside capture (allocator pools)
+        ops.curl_layer_forward(static_in, None, L, R, H)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out, static_reg = ops.curl_layer_forward(static_in, None, L, R, H)
+    for name in ("img", "img8"):
+        static_in.copy_(T(c[name], dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert max_err(N(static_out), c[f"s01_{name}_ones_out"]) <= 1e-5
+        np.testing.assert_allclose(N(static_reg), c[f"s01_{name}_ones_reg"], rtol=2e-6)
