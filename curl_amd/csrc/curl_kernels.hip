@@ -787,6 +787,98 @@ __global__ __launch_bounds__(256) void psnr_final_kernel(const float* partial, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward of the polynomial path: d loss / d coeffs  (autograd of model.py:499-520 w.r.t. R, L, H)
+// ------------------------------------------------------------------------------------------------
+#define TRI_PXT 16  // pixels per thread in the accumulation pass (amortises the 3*T-value block reduction)
+// pass 1: per pixel, the 9 colour variables (planes 0..8) and the 9 upstream gradients g_P[s][o] (planes 9..17)
+template <int V>
+__global__ __launch_bounds__(256) void trispace_bwd_px_kernel(const float* img, const float* coeffs, const float* gout,
+                                                              float* pxbuf, unsigned HW, unsigned W, float fW, float fH,
+                                                              int residual_only) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+  __shared__ float s_coef[9 * NC];
+  const unsigned b = blockIdx.y;
+  const float* table = coeffs + (size_t)b * 9 * NC;
+  for (int i = threadIdx.x; i < 9 * NC; i += 256) s_coef[i] = table[OpTriSpace<V>::stage_index(i)];
+  __syncthreads();
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= HW) return;
+  const size_t o = (size_t)b * 3 * HW + i;
+  unsigned row = i / W, col = i - row * W;
+  float vars[3][3], gP[3][3];
+  trispace_bwd_px<V, true>(Px{img[o], img[o + HW], img[o + 2 * (size_t)HW]}, (float)col / fW, (float)row / fH, s_coef,
+                           Px{gout[o], gout[o + HW], gout[o + 2 * (size_t)HW]}, residual_only != 0, vars, gP);
+  float* q = pxbuf + (size_t)b * 18 * HW + i;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      q[(size_t)(s * 3 + c) * HW] = vars[s][c];
+      q[(size_t)(9 + s * 3 + c) * HW] = gP[s][c];
+    }
+}
+// pass 2: block (tile of 256*TRI_PXT pixels, space s, image b) accumulates g_P[s][o] * m_t for chunk C of the
+// monomials in registers, reduces over the block, writes one row of partials.
+template <int V, int C>
+__global__ __launch_bounds__(256) void trispace_coef_grad_kernel(const float* pxbuf, float* partial, unsigned HW, unsigned W,
+                                                                 float fW, float fH, unsigned tiles) {
+  constexpr int NC = PolyEval<V>::kCoeffs, T = PolyEval<V>::kChunk;
+  __shared__ float sPart[4][3 * T];
+  const unsigned tile = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  const float* base = pxbuf + (size_t)b * 18 * HW;
+  float acc[3][T];
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[o][j] = 0.0f;
+  for (int k = 0; k < TRI_PXT; ++k) {
+    unsigned i = tile * (256u * TRI_PXT) + k * 256u + threadIdx.x;
+    if (i < HW) {
+      float v[V], g[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c] = base[(size_t)(s * 3 + c) * HW + i];
+        g[c] = base[(size_t)(9 + s * 3 + c) * HW + i];
+      }
+      if (V == 5) {
+        unsigned row = i / W, col = i - row * W;
+        v[V - 2] = (float)col / fW;
+        v[V - 1] = (float)row / fH;
+      }
+      coef_grad_accumulate<V, C>(acc, v, g);
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      float x = acc[o][j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (lane_id == 0) sPart[wave][o * T + j] = x;
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 3 * T; idx += 256) {
+    int o = idx / T, j = idx - o * T;
+    int t = C * T + j;
+    if (t < NC)
+      partial[((size_t)b * tiles + tile) * 9 * NC + (s * 3 + o) * NC + t] =
+          (sPart[0][idx] + sPart[1][idx]) + (sPart[2][idx] + sPart[3][idx]);
+  }
+}
+// pass 3: fixed-order float64 sum of the tile partials -> grad_coeffs [B,3,3,NC]
+__global__ __launch_bounds__(256) void trispace_coef_final_kernel(const float* partial, float* gcoef, unsigned tiles, int n) {
+  const unsigned b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const float* p = partial + (size_t)b * tiles * n + k;
+  double a = 0.0;
+  for (unsigned t = 0; t < tiles; ++t) a += (double)p[(size_t)t * n];
+  gcoef[(size_t)b * n + k] = (float)a;
+}
+
+// ------------------------------------------------------------------------------------------------
 // CURLLoss pointwise terms (model.py:78-116)
 // ------------------------------------------------------------------------------------------------
 #define LOSS_NSUM 5  // sum|p-t|, sum cos, sum|lab|, sum|cone|, sum mask
@@ -1099,6 +1191,29 @@ static int launch_chain(const float* in, float* out, const float* knots, unsigne
 }
 
 static int chain_mode(unsigned flags) { return (flags & CURL_F_EXACT_ORDER) ? 1 : (flags & CURL_F_PWL) ? 2 : 0; }
+
+static unsigned tri_tiles(size_t HW) { return (unsigned)((HW + 256u * TRI_PXT - 1) / (256u * TRI_PXT)); }
+
+template <int V>
+static hipError_t launch_trispace_bwd(const float* img, const float* coeffs, const float* gout, float* gcoef, float* pxbuf,
+                                      float* partial, int B, int H, int W, int residual_only, hipStream_t s) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+  unsigned HW = (unsigned)((size_t)H * W), tiles = tri_tiles(HW);
+  hipLaunchKernelGGL(trispace_bwd_px_kernel<V>, dim3((HW + 255u) / 256u, (unsigned)B), dim3(256), 0, s, img, coeffs, gout,
+                     pxbuf, HW, (unsigned)W, (float)W, (float)H, residual_only);
+  dim3 g2(tiles, 3, (unsigned)B);
+  hipLaunchKernelGGL((trispace_coef_grad_kernel<V, 0>), g2, dim3(256), 0, s, pxbuf, partial, HW, (unsigned)W, (float)W,
+                     (float)H, tiles);
+  if constexpr (PolyEval<V>::kChunks > 1) {
+    hipLaunchKernelGGL((trispace_coef_grad_kernel<V, 1>), g2, dim3(256), 0, s, pxbuf, partial, HW, (unsigned)W, (float)W,
+                       (float)H, tiles);
+    hipLaunchKernelGGL((trispace_coef_grad_kernel<V, 2>), g2, dim3(256), 0, s, pxbuf, partial, HW, (unsigned)W, (float)W,
+                       (float)H, tiles);
+  }
+  hipLaunchKernelGGL(trispace_coef_final_kernel, dim3((9 * NC + 255) / 256, (unsigned)B), dim3(256), 0, s, partial, gcoef,
+                     tiles, 9 * NC);
+  return hipGetLastError();
+}
 
 extern "C" {
 
@@ -1437,6 +1552,33 @@ int curl_loss_terms_bwd_f32(const float* pred, const float* target, const void* 
                      mask_kind ? mask : nullptr, mask_kind, weights, grad_L_pred, grad_pred, HW);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "loss_terms_bwd_kernel");
+  return 0;
+}
+
+size_t curl_trispace_bwd_scratch_bytes(int B, int H, int W, int num_coeffs) {
+  if (B <= 0 || H <= 0 || W <= 0 || (num_coeffs != 126 && num_coeffs != 35)) return 0;
+  size_t HW = (size_t)H * W;
+  return ((size_t)B * 18 * HW + (size_t)B * tri_tiles(HW) * 9 * num_coeffs) * sizeof(float);
+}
+
+int curl_trispace_bwd_f32(const float* img, const float* coeffs, const float* grad_out, float* grad_coeffs, void* scratch,
+                          size_t scratch_bytes, int B, int H, int W, int num_coeffs, unsigned flags,
+                          curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, grad_out, B, H, W)) return rc;
+  if (!coeffs || !grad_coeffs) return fail(CURL_E_NULL, "coeffs / grad_coeffs is NULL");
+  if (num_coeffs != 126 && num_coeffs != 35) return fail(CURL_E_KNOTS, "num_coeffs must be 126 or 35");
+  if (int rc = check_flags(flags, CURL_F_RESIDUAL_ONLY)) return rc;
+  if (!scratch || (uintptr_t)scratch % 16 || scratch_bytes < curl_trispace_bwd_scratch_bytes(B, H, W, num_coeffs))
+    return fail(CURL_E_WORKSPACE, "scratch missing, misaligned or smaller than curl_trispace_bwd_scratch_bytes");
+  size_t HW = (size_t)H * W;
+  float* pxbuf = (float*)scratch;
+  float* partial = pxbuf + (size_t)B * 18 * HW;
+  int ro = (flags & CURL_F_RESIDUAL_ONLY) ? 1 : 0;
+  hipError_t e = (num_coeffs == 126)
+                     ? launch_trispace_bwd<5>(img, coeffs, grad_out, grad_coeffs, pxbuf, partial, B, H, W, ro, (hipStream_t)stream)
+                     : launch_trispace_bwd<3>(img, coeffs, grad_out, grad_coeffs, pxbuf, partial, B, H, W, ro, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "trispace backward kernels");
   return 0;
 }
 

@@ -10,7 +10,7 @@
 // ~2.6 kFLOP per pixel: this kernel is VALU-bound by a wide margin (no MFMA shape fits: the contraction has
 // 3 output columns per 126-deep dot product, 3/16 of the smallest f32 MFMA tile, at the VALU's own rate).
 #pragma once
-#include "curl_math.h"
+#include "curl_math_bwd.h"
 
 namespace curlm {
 
@@ -45,6 +45,9 @@ struct PolyEval<5> {
   template <class F, bool SEQ, int NP>
   static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][5], const float* c) { poly_d4_v5<F, SEQ, NP>(out, v, c); }
   static CURL_HD int order(int pos) { return kPolyOrder_d4_v5[pos]; }
+  static constexpr int kChunk = 42, kChunks = 3;
+  template <int C>
+  static CURL_HD void monomials(float (&m)[42], const float (&pw)[5][5]) { mono_d4_v5<C>(m, pw); }
 };
 template <>
 struct PolyEval<3> {
@@ -52,6 +55,9 @@ struct PolyEval<3> {
   template <class F, bool SEQ, int NP>
   static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][3], const float* c) { poly_d4_v3<F, SEQ, NP>(out, v, c); }
   static CURL_HD int order(int pos) { return kPolyOrder_d4_v3[pos]; }
+  static constexpr int kChunk = 35, kChunks = 1;
+  template <int C>
+  static CURL_HD void monomials(float (&m)[35], const float (&pw)[3][5]) { mono_d4_v3<C>(m, pw); }
 };
 
 // out[o][i] = P_o(vars[.][i]) for the N pixels of a lane; coef = [3][NC] of one image and one space, in the
@@ -204,6 +210,67 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
       p.c2[i] = clamp01(p.c2[i] + res[2][i]);
     }
   }
+}
+
+// ---------------------------------------------------------------- backward of the polynomial path
+// Training the fork's live model needs d loss / d coeffs only (the image is data).  Per pixel and space s:
+//   y_s = conv_s(sigmoid(P_s(vars_s))),  residual = sum_s 2 (y_s - 0.5),  out = clamp(img + residual)  [or residual]
+//   g_P[s][o] = conv_s'(sigma)^T (2 g_res) * sigma (1 - sigma),   d coeffs[s][o][t] += g_P[s][o] * m_t(vars_s)
+// Pass 1 (this function) emits, per pixel, the 9 g_P values and the 9 colour variables (coordinates are
+// recomputed); pass 2 accumulates the outer products with the monomials (coef_grad_accumulate).
+template <int V, bool SEQ>
+CURL_HD void trispace_bwd_px(Px in, float xw, float yh, const float* coef, Px gout, bool residual_only,
+                             float (&vars)[3][3], float (&gP)[3][3]) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+  Px sp[3] = {in, rgb2lab(in), rgb2hsv(in)};
+  float sig[3][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    vars[s][0] = sp[s].c0, vars[s][1] = sp[s].c1, vars[s][2] = sp[s].c2;
+    float v[V][1], o[3][1];
+    v[0][0] = sp[s].c0, v[1][0] = sp[s].c1, v[2][0] = sp[s].c2;
+    if (V == 5) v[V - 2][0] = xw, v[V - 1][0] = yh;
+    poly3_n<V, 1, SEQ>(o, v, coef + s * 3 * NC);
+    float flat[3] = {o[0][0], o[1][0], o[2][0]};
+    sigmoid_run(flat);
+    sig[s][0] = flat[0], sig[s][1] = flat[1], sig[s][2] = flat[2];
+  }
+  Px y1 = lab2rgb(Px{sig[1][0], sig[1][1], sig[1][2]}), y2 = hsv2rgb(Px{sig[2][0], sig[2][1], sig[2][2]});
+  float res[3] = {2.0f * (sig[0][0] - 0.5f) + 2.0f * (y1.c0 - 0.5f) + 2.0f * (y2.c0 - 0.5f),
+                  2.0f * (sig[0][1] - 0.5f) + 2.0f * (y1.c1 - 0.5f) + 2.0f * (y2.c1 - 0.5f),
+                  2.0f * (sig[0][2] - 0.5f) + 2.0f * (y1.c2 - 0.5f) + 2.0f * (y2.c2 - 0.5f)};
+  Px g_res = gout;
+  if (!residual_only)  // generate_image: clamp(img + residual, 0, 1)
+    g_res = Px{gout.c0 * pass01(in.c0 + res[0]), gout.c1 * pass01(in.c1 + res[1]), gout.c2 * pass01(in.c2 + res[2])};
+  Px gy{2.0f * g_res.c0, 2.0f * g_res.c1, 2.0f * g_res.c2};
+  Px gs[3] = {gy, lab2rgb_bwd(Px{sig[1][0], sig[1][1], sig[1][2]}, gy), hsv2rgb_bwd(Px{sig[2][0], sig[2][1], sig[2][2]}, gy)};
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    gP[s][0] = gs[s].c0 * sig[s][0] * (1.0f - sig[s][0]);
+    gP[s][1] = gs[s].c1 * sig[s][1] * (1.0f - sig[s][1]);
+    gP[s][2] = gs[s].c2 * sig[s][2] * (1.0f - sig[s][2]);
+  }
+}
+
+// acc[o][j] += gP[o] * m_{C*chunk + j}(v) for one pixel and one chunk of the monomials
+template <int V, int C>
+CURL_HD void coef_grad_accumulate(float (&acc)[3][PolyEval<V>::kChunk], const float (&v)[V], const float (&gP)[3]) {
+  constexpr int T = PolyEval<V>::kChunk;
+  float pw[V][5];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    pw[k][0] = 1.0f;
+    pw[k][1] = v[k];
+    pw[k][2] = v[k] * v[k];
+    pw[k][3] = pw[k][2] * v[k];
+    pw[k][4] = pw[k][2] * pw[k][2];
+  }
+  float m[T];
+  PolyEval<V>::template monomials<C>(m, pw);
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[o][j] = fmaf(gP[o], m[j], acc[o][j]);
 }
 
 }  // namespace curlm

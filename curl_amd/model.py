@@ -182,6 +182,24 @@ def _powers(degree, num_variables):
     return rows
 
 
+class _TriSpaceFn(torch.autograd.Function):
+    """Autograd node around the fused polynomial kernels: gradient w.r.t. the coefficients only."""
+
+    @staticmethod
+    def forward(ctx, img, coeffs, residual_only):
+        ctx.save_for_backward(img, coeffs)
+        ctx.residual_only = residual_only
+        return ops.trispace_forward(img, coeffs, residual_only=residual_only)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, coeffs = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("curl_amd: the polynomial path differentiates w.r.t. the coefficients only "
+                                      "(the image is data in main.py's train step)")
+        return None, ops.trispace_backward(img, coeffs, grad_out.contiguous(), ctx.residual_only), None
+
+
 class ChannelPolyLayer(nn.Module):
     """model.py:206-333.  forward(img [B,V,H,W], coeffs [B,num_out,num_coeffs]) -> [B,num_out,H,W].
     The HIP kernel covers what the fork uses: degree 4, V = 5 or 3, num_out = 3."""
@@ -261,8 +279,11 @@ class TriSpaceRegNet(nn.Module):
         return coeffs[:, 0], coeffs[:, 1], coeffs[:, 2]
 
     def generate_residual(self, img, R, L, H):
-        """model.py:499-515, one kernel."""
-        return ops.trispace_forward(img, torch.stack((R, L, H), 1), residual_only=True)
+        """model.py:499-515, one kernel (differentiable w.r.t. R, L, H)."""
+        coeffs = torch.stack((R, L, H), 1)
+        if torch.is_grad_enabled() and coeffs.requires_grad:
+            return _TriSpaceFn.apply(img, coeffs, True)
+        return ops.trispace_forward(img, coeffs, residual_only=True)
 
     @staticmethod
     def generate_image(img, residual):
@@ -274,6 +295,8 @@ class TriSpaceRegNet(nn.Module):
         is_train=True returns the image clamp(input + residual), else the residual."""
         coeffs = self.backbone(img * mask).reshape(img.shape[0], self.num_spaces, self.num_channels, self.num_coeffs)
         input_img = img if target_img is None else target_img
+        if torch.is_grad_enabled() and coeffs.requires_grad:
+            return _TriSpaceFn.apply(input_img, coeffs, not self.is_train)
         return ops.trispace_forward(input_img, coeffs, residual_only=not self.is_train)
 
 

@@ -244,6 +244,22 @@ def trispace_forward(img, coeffs, residual_only=False, flags=0):
     return out
 
 
+def trispace_backward(img, coeffs, grad_out, residual_only=False):
+    """d loss / d coeffs [B,3,3,NC] of trispace_forward, given grad_out = d loss / d out."""
+    lib = _lib.load()
+    img, grad_out = _image(img), _image(grad_out, "grad_out")
+    B, _, H, W = img.shape
+    c = coeffs.to(torch.float32).contiguous()
+    nc = c.shape[3]
+    g = torch.empty_like(c)
+    nbytes = lib.curl_trispace_bwd_scratch_bytes(B, H, W, nc)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=img.device)
+    rc = lib.curl_trispace_bwd_f32(img.data_ptr(), c.data_ptr(), grad_out.data_ptr(), g.data_ptr(), scratch.data_ptr(),
+                                   nbytes, B, H, W, nc, _lib.F_RESIDUAL_ONLY if residual_only else 0, _stream(img))
+    _lib.check(rc, "curl_trispace_bwd_f32")
+    return g
+
+
 def poly_layer(img, coeffs):
     """ChannelPolyLayer(degree=4) / Deg4MobilePolyLayer forward (model.py:295-333, 399-415):
     img [B,V,H,W] with V = 5 or 3, coeffs [B,3,126|35] -> [B,3,H,W]."""

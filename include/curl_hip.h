@@ -146,6 +146,16 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind,
 int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
                           int num_coeffs, unsigned flags, curl_stream_t stream);
 
+/* replaces: autograd of curl_trispace_fwd_f32 w.r.t. the coefficients (what loss.backward() runs through
+ *           TriSpaceRegNet.generate_residual, main.py:287) -- the image is data, its gradient is not produced.
+ * grad_out [B,3,H,W] -> grad_coeffs [B,3,3,num_coeffs] (ASSIGNED).  flags: CURL_F_RESIDUAL_ONLY as in the forward.
+ * Three passes: per-pixel upstream gradients, register-tiled outer products with the monomials, fixed-order
+ * float64 reduction (no atomics).  scratch: curl_trispace_bwd_scratch_bytes (72 B per pixel + tile partials). */
+size_t curl_trispace_bwd_scratch_bytes(int B, int H, int W, int num_coeffs);
+int curl_trispace_bwd_f32(const float* img, const float* coeffs, const float* grad_out, float* grad_coeffs,
+                          void* scratch, size_t scratch_bytes, int B, int H, int W, int num_coeffs,
+                          unsigned flags, curl_stream_t stream);
+
 /* replaces: ChannelPolyLayer(degree=4).forward / Deg4MobilePolyLayer.forward  model.py:295-333, 399-415
  * img [B,num_variables,H,W] (num_variables 5 or 3), coeffs [B,3,num_coeffs] -> out [B,3,H,W]. */
 int curl_poly_layer_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,

@@ -152,6 +152,15 @@ def twin():
             lib.twin_loss_terms_bwd(P(pred), P(tgt), P(mask), P(w4), P(gLp), P(g), B, ctypes.c_long(Hh * W))
             return g
 
+        @staticmethod
+        def trispace_bwd(img, coeffs, gout, residual_only=False):
+            img, coeffs, gout = f32(img), f32(coeffs), f32(gout)
+            B, _, Hh, W = img.shape
+            V = 5 if coeffs.shape[-1] == 126 else 3
+            g = np.empty_like(coeffs)
+            lib.twin_trispace_bwd(P(img), P(coeffs), P(gout), P(g), B, Hh, W, V, int(residual_only))
+            return g
+
     return Twin
 
 

@@ -154,3 +154,50 @@ def test_curl_loss_module_vs_oracle(dev):
     assert abs(float(loss) - float(ref)) <= 2e-6
     d = (p.grad.cpu() - pc.grad).abs()
     assert float(torch.quantile(d.flatten(), 0.995)) <= 2e-4 * float(pc.grad.abs().max())
+
+
+@pytest.mark.parametrize("nc,residual_only,shape", [(126, False, (2, 12, 20)), (126, True, (1, 70, 131)),
+                                                      (35, False, (3, 33, 65)), (126, False, (1, 130, 257))])
+def test_trispace_backward_vs_oracle_autograd(ops, dev, nc, residual_only, shape):
+    """d loss / d coeffs of the fused polynomial path (C ABI) vs autograd through the oracle; sizes straddle the
+    4096-pixel accumulation tile (1, 3 and 9 tiles, ragged)."""
+    from oracle import curl_oracle as O
+    g = torch.Generator().manual_seed(nc + residual_only + shape[1])
+    B, H, W = shape
+    img = torch.rand(B, 3, H, W, generator=g)
+    coeffs = (torch.randn(B, 3, 3, nc, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(B, 3, H, W, generator=g)
+    res = O.trispace_residual(img, coeffs[:, 0], coeffs[:, 1], coeffs[:, 2], spatial=(nc == 126))
+    out = res if residual_only else O.generate_image(img, res)
+    (out * w).sum().backward()
+    got = ops.trispace_backward(img.to(dev), coeffs.detach().to(dev), w.to(dev), residual_only=residual_only)
+    assert rel(got, coeffs.grad) <= 2e-4
+    again = ops.trispace_backward(img.to(dev), coeffs.detach().to(dev), w.to(dev), residual_only=residual_only)
+    assert torch.equal(got, again)  # fixed-order reduction: bit-reproducible
+
+
+def test_trispace_regnet_train_step(dev):
+    """TriSpaceRegNet.forward under autograd: the backbone's parameters receive the same gradients as with the
+    oracle's differentiable polynomial ops downstream of the same backbone."""
+    from curl_amd import model as M
+    from oracle import curl_oracle as O
+    torch.manual_seed(3)
+    net = M.TriSpaceRegNet(spatial=True).to(dev)
+    net.eval()  # batch-norm in inference mode so both passes see the same statistics
+    img = torch.rand(2, 3, 48, 64, device=dev)
+    mask = torch.ones(2, 1, 48, 64, device=dev)
+    tgt = torch.rand(2, 3, 48, 64, device=dev)
+    out = net(img, mask)
+    assert out.requires_grad
+    ((out - tgt) ** 2).mean().backward()
+    got = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert got, "no parameter received a gradient"
+    net.zero_grad()
+    R, L, H = net.generate_coefficients(img, mask)
+    ref_out = O.generate_image(img, O.trispace_residual(img, R, L, H))  # torch-eager on the device, autograd
+    ((ref_out - tgt) ** 2).mean().backward()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if p.grad is not None and float(p.grad.abs().max()) > 0:
+            worst = max(worst, rel(got[k], p.grad))
+    assert worst <= 2e-3, worst

@@ -59,3 +59,19 @@ def test_twin_trispace(twin, golden, s, tol):
         assert max_err(twin.trispace(g[nm], g[s + "_coeffs"], residual_only=True), g[f"{s}_{nm}_residual"]) <= tol, nm
         assert max_err(twin.trispace(g[nm], g[s + "_coeffs"]), g[f"{s}_{nm}_image"]) <= tol, nm
     assert max_err(twin.trispace(g["img"], g[s + "_coeffs35"], residual_only=True), g[f"{s}_img_residual_nonspatial"]) <= tol
+
+
+@pytest.mark.parametrize("nc,residual_only", [(126, False), (126, True), (35, False)])
+def test_twin_trispace_backward_vs_oracle_autograd(twin, nc, residual_only):
+    """d loss / d coeffs of the fused polynomial path vs autograd through the oracle (= the reference's ops)."""
+    g = torch.Generator().manual_seed(nc + residual_only)
+    B, H, W = 2, 12, 20
+    img = torch.rand(B, 3, H, W, generator=g)
+    coeffs = (torch.randn(B, 3, 3, nc, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(B, 3, H, W, generator=g)
+    res = O.trispace_residual(img, coeffs[:, 0], coeffs[:, 1], coeffs[:, 2], spatial=(nc == 126))
+    out = res if residual_only else O.generate_image(img, res)
+    (out * w).sum().backward()
+    got = twin.trispace_bwd(img.numpy(), coeffs.detach().numpy(), w.numpy(), residual_only)
+    ref = coeffs.grad.numpy()
+    assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()

@@ -239,4 +239,55 @@ int twin_loss_terms_bwd(const float* pred, const float* tgt, const float* mask, 
     }
   return 0;
 }
+
+}  // extern "C"
+
+// d loss / d coeffs [B,3,3,NC] of twin_trispace, given gout = d loss / d out.
+template <int V>
+static void trispace_bwd_host(const float* img, const float* coeffs, const float* gout, float* gcoef, int B, int H, int W,
+                              int residual_only) {
+  constexpr int NC = PolyEval<V>::kCoeffs, T = PolyEval<V>::kChunk;
+  const long HW = (long)H * W;
+  for (int b = 0; b < B; ++b) {
+    std::vector<double> acc(9 * NC, 0.0);
+    for (long i = 0; i < HW; ++i) {
+      const float* p = img + (size_t)b * 3 * HW + i;
+      const float* g = gout + (size_t)b * 3 * HW + i;
+      float xw = (float)(i % W) / (float)W, yh = (float)(i / W) / (float)H;
+      float vars[3][3], gP[3][3];
+      trispace_bwd_px<V, false>(Px{p[0], p[HW], p[2 * HW]}, xw, yh, coeffs + (size_t)b * 9 * NC, Px{g[0], g[HW], g[2 * HW]},
+                                residual_only != 0, vars, gP);
+      for (int s = 0; s < 3; ++s) {
+        float v[V];
+        v[0] = vars[s][0], v[1] = vars[s][1], v[2] = vars[s][2];
+        if (V == 5) v[V - 2] = xw, v[V - 1] = yh;
+        float a[3][T];
+        auto flush = [&](int c) {
+          for (int o = 0; o < 3; ++o)
+            for (int j = 0; j < T; ++j)
+              if (c * T + j < NC) acc[(s * 3 + o) * NC + c * T + j] += a[o][j];
+        };
+        for (int o = 0; o < 3; ++o) for (int j = 0; j < T; ++j) a[o][j] = 0.0f;
+        coef_grad_accumulate<V, 0>(a, v, gP[s]);
+        flush(0);
+        if constexpr (PolyEval<V>::kChunks > 1) {
+          for (int o = 0; o < 3; ++o) for (int j = 0; j < T; ++j) a[o][j] = 0.0f;
+          coef_grad_accumulate<V, 1>(a, v, gP[s]);
+          flush(1);
+          for (int o = 0; o < 3; ++o) for (int j = 0; j < T; ++j) a[o][j] = 0.0f;
+          coef_grad_accumulate<V, 2>(a, v, gP[s]);
+          flush(2);
+        }
+      }
+    }
+    for (int k = 0; k < 9 * NC; ++k) gcoef[(size_t)b * 9 * NC + k] = (float)acc[k];
+  }
+}
+extern "C" {
+int twin_trispace_bwd(const float* img, const float* coeffs, const float* gout, float* gcoef, int B, int H, int W, int V,
+                      int residual_only) {
+  if (V == 5) trispace_bwd_host<5>(img, coeffs, gout, gcoef, B, H, W, residual_only);
+  else trispace_bwd_host<3>(img, coeffs, gout, gcoef, B, H, W, residual_only);
+  return 0;
+}
 }

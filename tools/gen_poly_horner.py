@@ -111,6 +111,28 @@ CURL_HD void poly_d{degree}_v{nvars}(F (&out)[NP], const F (&v)[NP][{nvars}], co
 """
 
 
+def gen_monomials(degree, nvars, chunk):
+    """Straight-line code for the monomials themselves (the backward needs them: d out_o / d coef[o][t] = m_t):
+    m[j] = prod_k pw[k][e_k] for the terms [c*chunk, (c+1)*chunk) of the reference order, from the power table
+    pw[k][e] = v_k^e (e = 1..degree; exponent 0 factors are skipped)."""
+    table = powers(degree, nvars)
+    n_chunks = (len(table) + chunk - 1) // chunk
+    out = [f"// monomials of degree <= {degree} in {nvars} variables, {n_chunks} chunk(s) of {chunk}",
+           f"template <int C>\nCURL_HD void mono_d{degree}_v{nvars}(float (&m)[{chunk}], const float (&pw)[{nvars}][{degree + 1}]) {{"]
+    for c in range(n_chunks):
+        out.append(f"  if constexpr (C == {c}) {{")
+        for j in range(chunk):
+            t = c * chunk + j
+            if t >= len(table):
+                out.append(f"    m[{j}] = 0.0f;")
+                continue
+            factors = [f"pw[{k}][{e}]" for k, e in enumerate(table[t]) if e > 0]
+            out.append(f"    m[{j}] = {' * '.join(factors) if factors else '1.0f'};")
+        out.append("  }")
+    out.append("}\n")
+    return "\n".join(out)
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "curl_amd", "csrc", "poly_horner.inc")
@@ -121,6 +143,8 @@ def main():
     for degree, nvars in ((4, 5), (4, 3)):
         table, code = gen(degree, nvars)
         parts.append(code)
+    parts.append(gen_monomials(4, 5, 42))
+    parts.append(gen_monomials(4, 3, 35))
     open(out, "w").write("\n".join(parts))
     print("wrote", out)
 
