@@ -789,82 +789,168 @@ __global__ __launch_bounds__(256) void psnr_final_kernel(const float* partial, f
 // ------------------------------------------------------------------------------------------------
 // backward of the polynomial path: d loss / d coeffs  (autograd of model.py:499-520 w.r.t. R, L, H)
 // ------------------------------------------------------------------------------------------------
-#define TRI_PXT 16  // pixels per thread in the accumulation pass (amortises the 3*T-value block reduction)
+#define TRI_BWD_N 2  // pixels per lane in pass 1: one packed Horner chain (4 per lane spilled: 9 KB scratch)
 // pass 1: per pixel, the 9 colour variables (planes 0..8) and the 9 upstream gradients g_P[s][o] (planes 9..17)
 template <int V>
-__global__ __launch_bounds__(256) void trispace_bwd_px_kernel(const float* img, const float* coeffs, const float* gout,
-                                                              float* pxbuf, unsigned HW, unsigned W, float fW, float fH,
-                                                              int residual_only) {
-  constexpr int NC = PolyEval<V>::kCoeffs;
+__global__ __launch_bounds__(256, 2) void trispace_bwd_px_kernel(const float* img, const float* coeffs, const float* gout,
+                                                                 float* pxbuf, unsigned HW, unsigned W, float fW, float fH,
+                                                                 int residual_only, int vec_ok) {
+  constexpr int NC = PolyEval<V>::kCoeffs, N = TRI_BWD_N;
+  typedef float VT __attribute__((ext_vector_type(N)));
   __shared__ float s_coef[9 * NC];
   const unsigned b = blockIdx.y;
   const float* table = coeffs + (size_t)b * 9 * NC;
   for (int i = threadIdx.x; i < 9 * NC; i += 256) s_coef[i] = table[OpTriSpace<V>::stage_index(i)];
   __syncthreads();
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= HW) return;
-  const size_t o = (size_t)b * 3 * HW + i;
-  unsigned row = i / W, col = i - row * W;
-  float vars[3][3], gP[3][3];
-  trispace_bwd_px<V, true>(Px{img[o], img[o + HW], img[o + 2 * (size_t)HW]}, (float)col / fW, (float)row / fH, s_coef,
-                           Px{gout[o], gout[o + HW], gout[o + 2 * (size_t)HW]}, residual_only != 0, vars, gP);
-  float* q = pxbuf + (size_t)b * 18 * HW + i;
+  const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * N;
+  if (i0 >= HW) return;
+  const float* pi = img + (size_t)b * 3 * HW;
+  const float* pg = gout + (size_t)b * 3 * HW;
+  PxN<N> in, g;
+  float xw[N], yh[N];
+  if (vec_ok) {  // HW % N == 0 and planes aligned to the vector: i0 + N - 1 < HW
+    auto unpack = [](float (&d)[N], const float* p) {
+      VT t = *(const VT*)p;
+#pragma unroll
+      for (int k = 0; k < N; ++k) d[k] = t[k];
+    };
+    unpack(in.c0, pi + i0), unpack(in.c1, pi + HW + i0), unpack(in.c2, pi + 2 * (size_t)HW + i0);
+    unpack(g.c0, pg + i0), unpack(g.c1, pg + HW + i0), unpack(g.c2, pg + 2 * (size_t)HW + i0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      unsigned i = min(i0 + k, HW - 1);
+      in.c0[k] = pi[i], in.c1[k] = pi[HW + i], in.c2[k] = pi[2 * (size_t)HW + i];
+      g.c0[k] = pg[i], g.c1[k] = pg[HW + i], g.c2[k] = pg[2 * (size_t)HW + i];
+    }
+  }
+  unsigned row = i0 / W, col = i0 - row * W;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    xw[k] = (float)col / fW, yh[k] = (float)row / fH;
+    if (++col == W) col = 0, ++row;
+  }
+  float vars[3][3][N], gP[3][3][N];
+  trispace_bwd_n<V, N, true>(in, xw, yh, s_coef, g, residual_only != 0, vars, gP);
+  float* q = pxbuf + (size_t)b * 18 * HW;
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      q[(size_t)(s * 3 + c) * HW] = vars[s][c];
-      q[(size_t)(9 + s * 3 + c) * HW] = gP[s][c];
+      float* qv = q + (size_t)(s * 3 + c) * HW + i0;
+      float* qg = q + (size_t)(9 + s * 3 + c) * HW + i0;
+      if (vec_ok) {
+        VT tv, tg;
+#pragma unroll
+        for (int k = 0; k < N; ++k) tv[k] = vars[s][c][k], tg[k] = gP[s][c][k];
+        *(VT*)qv = tv, *(VT*)qg = tg;
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (i0 + k < HW) qv[k] = vars[s][c][k], qg[k] = gP[s][c][k];
+      }
     }
 }
-// pass 2: block (tile of 256*TRI_PXT pixels, space s, image b) accumulates g_P[s][o] * m_t for chunk C of the
-// monomials in registers, reduces over the block, writes one row of partials.
+// wave-wide sum in 6 DPP adds (VALU rate; __shfl_xor compiles to ds_bpermute + a full wait each): the row's 16
+// lanes by quad_perm / half-mirror / mirror, then row_bcast15 and row_bcast31.  The total is in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+// stage-major over a lane's M accumulators: consecutive DPP adds are independent (no wait states between them)
+template <int CTRL, int ROW_MASK, int R, int M>
+__device__ __forceinline__ void dpp_add_all(float (&x)[R][M]) {
+#pragma unroll
+  for (int o = 0; o < R; ++o)
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[o][j] = dpp_add<CTRL, ROW_MASK>(x[o][j]);
+  CURL_FENCE();
+}
+template <int R, int M>
+__device__ __forceinline__ void wave_sum_lane63(float (&x)[R][M]) {
+  dpp_add_all<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  dpp_add_all<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  dpp_add_all<0x141, 0xF>(x);  // row_half_mirror
+  dpp_add_all<0x140, 0xF>(x);  // row_mirror: every lane of a row holds the row's sum
+  dpp_add_all<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  dpp_add_all<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
+}
+// pass 2: block (tile of 256*ppt pixels; space s and monomial chunk C; image b) accumulates g_P[s][o] * m_t in
+// registers, reduces over the block, writes one row of partials.
+struct CoefGradArgs {
+  const float* pxbuf;
+  float* partial;
+  unsigned HW, W, tiles, ppt, items;  // items = B * 3 * tiles work items (image, space, tile)
+  unsigned step_rows, step_cols;      // 256 / W, 256 % W: how (row, col) advances per loop step
+  float fW, fH;
+};
 template <int V, int C>
-__global__ __launch_bounds__(256) void trispace_coef_grad_kernel(const float* pxbuf, float* partial, unsigned HW, unsigned W,
-                                                                 float fW, float fH, unsigned tiles) {
+__device__ __forceinline__ void coef_grad_block(const CoefGradArgs& a, unsigned b, unsigned s, unsigned tile,
+                                                float (*sPart)[3 * PolyEval<V>::kChunk]) {
   constexpr int NC = PolyEval<V>::kCoeffs, T = PolyEval<V>::kChunk;
-  __shared__ float sPart[4][3 * T];
-  const unsigned tile = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
-  const float* base = pxbuf + (size_t)b * 18 * HW;
+  const unsigned HW = a.HW;
+  const float* base = a.pxbuf + (size_t)b * 18 * HW + (size_t)(s * 3) * HW;
   float acc[3][T];
 #pragma unroll
   for (int o = 0; o < 3; ++o)
 #pragma unroll
     for (int j = 0; j < T; ++j) acc[o][j] = 0.0f;
-  for (int k = 0; k < TRI_PXT; ++k) {
-    unsigned i = tile * (256u * TRI_PXT) + k * 256u + threadIdx.x;
-    if (i < HW) {
-      float v[V], g[3];
+  unsigned i = tile * 256u * a.ppt + threadIdx.x;
+  unsigned row = i / a.W, col = i - row * a.W;
+  auto fetch = [&](float (&d)[6], unsigned at) {  // clamped: always a valid pixel, masked below
+    const float* p = base + min(at, HW - 1);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        v[c] = base[(size_t)(s * 3 + c) * HW + i];
-        g[c] = base[(size_t)(9 + s * 3 + c) * HW + i];
-      }
-      if (V == 5) {
-        unsigned row = i / W, col = i - row * W;
-        v[V - 2] = (float)col / fW;
-        v[V - 1] = (float)row / fH;
-      }
-      coef_grad_accumulate<V, C>(acc, v, g);
+    for (int c = 0; c < 3; ++c) d[c] = p[(size_t)c * HW], d[3 + c] = p[(size_t)(9 + c) * HW];
+  };
+  float cur[6], nxt[6];
+  fetch(cur, i);
+  for (unsigned k = 0; k < a.ppt; ++k) {
+    fetch(nxt, i + 256u);  // next step's operands are in flight while this step computes
+    float v[V], g[3];
+    const bool live = i < HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = cur[c], g[c] = live ? cur[3 + c] : 0.0f;
+    if (V == 5) {
+      v[V - 2] = (float)col / a.fW;
+      v[V - 1] = (float)row / a.fH;
     }
+    coef_grad_accumulate<V, C>(acc, v, g);
+    CURL_FENCE();  // keep the wait for the prefetch at the end of the step
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cur[c] = nxt[c];
+    i += 256u, row += a.step_rows, col += a.step_cols;
+    if (col >= a.W) col -= a.W, ++row;
   }
   const int wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+  wave_sum_lane63(acc);
 #pragma unroll
   for (int o = 0; o < 3; ++o)
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-      float x = acc[o][j];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-      if (lane_id == 0) sPart[wave][o * T + j] = x;
-    }
+    for (int j = 0; j < T; ++j)
+      if (lane_id == 63) sPart[wave][o * T + j] = acc[o][j];
   __syncthreads();
   for (int idx = threadIdx.x; idx < 3 * T; idx += 256) {
     int o = idx / T, j = idx - o * T;
     int t = C * T + j;
     if (t < NC)
-      partial[((size_t)b * tiles + tile) * 9 * NC + (s * 3 + o) * NC + t] =
+      a.partial[((size_t)b * a.tiles + tile) * 9 * NC + (s * 3 + o) * NC + t] =
           (sPart[0][idx] + sPart[1][idx]) + (sPart[2][idx] + sPart[3][idx]);
+  }
+}
+// 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (id % 8); the kChunks blocks of one work item re-read
+// the same 6 planes of the tile, so they get ids 8 apart: same XCD, same L2, dispatched together.
+template <int V>
+__global__ __launch_bounds__(256) void trispace_coef_grad_kernel(CoefGradArgs a) {
+  constexpr int CH = PolyEval<V>::kChunks;
+  __shared__ float sPart[4][3 * PolyEval<V>::kChunk];
+  const unsigned n = blockIdx.x, group = n / (8u * CH), r = n - group * (8u * CH);
+  const unsigned chunk = r >> 3, item = group * 8u + (r & 7u);  // block-uniform
+  if (item >= a.items) return;
+  const unsigned tile = item % a.tiles, bs = item / a.tiles, s = bs % 3u, b = bs / 3u;
+  if (chunk == 0) coef_grad_block<V, 0>(a, b, s, tile, sPart);
+  if constexpr (CH > 1) {
+    if (chunk == 1) coef_grad_block<V, 1>(a, b, s, tile, sPart);
+    if (chunk == 2) coef_grad_block<V, 2>(a, b, s, tile, sPart);
   }
 }
 // pass 3: fixed-order float64 sum of the tile partials -> grad_coeffs [B,3,3,NC]
@@ -1192,24 +1278,30 @@ static int launch_chain(const float* in, float* out, const float* knots, unsigne
 
 static int chain_mode(unsigned flags) { return (flags & CURL_F_EXACT_ORDER) ? 1 : (flags & CURL_F_PWL) ? 2 : 0; }
 
-static unsigned tri_tiles(size_t HW) { return (unsigned)((HW + 256u * TRI_PXT - 1) / (256u * TRI_PXT)); }
+// pixels per thread of the accumulation pass: enough to amortise the 3*T-value block reduction (>= 16), few enough
+// that the grid still covers the chip several times over (~2048 blocks)
+static unsigned tri_ppt(int B, size_t HW) {
+  size_t p = HW * 9 * (size_t)B / (256u * 2048u);
+  return (unsigned)(p < 16 ? 16 : (p > 64 ? 64 : p));
+}
+static unsigned tri_tiles(int B, size_t HW) {
+  size_t per = 256u * (size_t)tri_ppt(B, HW);
+  return (unsigned)((HW + per - 1) / per);
+}
 
 template <int V>
 static hipError_t launch_trispace_bwd(const float* img, const float* coeffs, const float* gout, float* gcoef, float* pxbuf,
                                       float* partial, int B, int H, int W, int residual_only, hipStream_t s) {
   constexpr int NC = PolyEval<V>::kCoeffs;
-  unsigned HW = (unsigned)((size_t)H * W), tiles = tri_tiles(HW);
-  hipLaunchKernelGGL(trispace_bwd_px_kernel<V>, dim3((HW + 255u) / 256u, (unsigned)B), dim3(256), 0, s, img, coeffs, gout,
-                     pxbuf, HW, (unsigned)W, (float)W, (float)H, residual_only);
-  dim3 g2(tiles, 3, (unsigned)B);
-  hipLaunchKernelGGL((trispace_coef_grad_kernel<V, 0>), g2, dim3(256), 0, s, pxbuf, partial, HW, (unsigned)W, (float)W,
-                     (float)H, tiles);
-  if constexpr (PolyEval<V>::kChunks > 1) {
-    hipLaunchKernelGGL((trispace_coef_grad_kernel<V, 1>), g2, dim3(256), 0, s, pxbuf, partial, HW, (unsigned)W, (float)W,
-                       (float)H, tiles);
-    hipLaunchKernelGGL((trispace_coef_grad_kernel<V, 2>), g2, dim3(256), 0, s, pxbuf, partial, HW, (unsigned)W, (float)W,
-                       (float)H, tiles);
-  }
+  unsigned HW = (unsigned)((size_t)H * W), ppt = tri_ppt(B, HW), tiles = tri_tiles(B, HW);
+  const unsigned va = 4 * TRI_BWD_N;
+  int vec_ok = (HW % TRI_BWD_N == 0) && ((uintptr_t)img % va == 0) && ((uintptr_t)gout % va == 0) && ((uintptr_t)pxbuf % va == 0);
+  unsigned threads = (HW + TRI_BWD_N - 1) / TRI_BWD_N;
+  hipLaunchKernelGGL(trispace_bwd_px_kernel<V>, dim3((threads + 255u) / 256u, (unsigned)B), dim3(256), 0, s, img, coeffs,
+                     gout, pxbuf, HW, (unsigned)W, (float)W, (float)H, residual_only, vec_ok);
+  CoefGradArgs a{pxbuf, partial, HW, (unsigned)W, tiles, ppt, (unsigned)B * 3u * tiles, 256u / (unsigned)W, 256u % (unsigned)W,
+                 (float)W, (float)H};
+  hipLaunchKernelGGL(trispace_coef_grad_kernel<V>, dim3((a.items + 7u) / 8u * 8u * PolyEval<V>::kChunks), dim3(256), 0, s, a);
   hipLaunchKernelGGL(trispace_coef_final_kernel, dim3((9 * NC + 255) / 256, (unsigned)B), dim3(256), 0, s, partial, gcoef,
                      tiles, 9 * NC);
   return hipGetLastError();
@@ -1558,7 +1650,7 @@ int curl_loss_terms_bwd_f32(const float* pred, const float* target, const void* 
 size_t curl_trispace_bwd_scratch_bytes(int B, int H, int W, int num_coeffs) {
   if (B <= 0 || H <= 0 || W <= 0 || (num_coeffs != 126 && num_coeffs != 35)) return 0;
   size_t HW = (size_t)H * W;
-  return ((size_t)B * 18 * HW + (size_t)B * tri_tiles(HW) * 9 * num_coeffs) * sizeof(float);
+  return ((size_t)B * 18 * HW + (size_t)B * tri_tiles(B, HW) * 9 * num_coeffs) * sizeof(float);
 }
 
 int curl_trispace_bwd_f32(const float* img, const float* coeffs, const float* grad_out, float* grad_coeffs, void* scratch,

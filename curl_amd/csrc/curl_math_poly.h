@@ -218,38 +218,68 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
 //   g_P[s][o] = conv_s'(sigma)^T (2 g_res) * sigma (1 - sigma),   d coeffs[s][o][t] += g_P[s][o] * m_t(vars_s)
 // Pass 1 (this function) emits, per pixel, the 9 g_P values and the 9 colour variables (coordinates are
 // recomputed); pass 2 accumulates the outer products with the monomials (coef_grad_accumulate).
+template <int V, int N, bool SEQ>
+CURL_HD void trispace_bwd_n(const PxN<N>& in, const float (&xw)[N], const float (&yh)[N], const float* coef,
+                            const PxN<N>& gout, bool residual_only, float (&vars)[3][3][N], float (&gP)[3][3][N]) {
+  constexpr int NC = PolyEval<V>::kCoeffs;
+  PxN<N> sp[3] = {in, in, in};
+  rgb2lab_n<N>(sp[1]);
+  rgb2hsv_n<N>(sp[2]);
+  float sig[3][3][N];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {  // forward recompute: the N pixels share the coefficient reads (poly3_n)
+    float v[V][N], o[3][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      vars[s][0][i] = v[0][i] = sp[s].c0[i];
+      vars[s][1][i] = v[1][i] = sp[s].c1[i];
+      vars[s][2][i] = v[2][i] = sp[s].c2[i];
+      if (V == 5) v[V - 2][i] = xw[i], v[V - 1][i] = yh[i];
+    }
+    poly3_n<V, N, SEQ>(o, v, coef + s * 3 * NC);
+    float flat[3 * N];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) flat[c * N + i] = o[c][i];
+    sigmoid_run(flat);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) sig[s][c][i] = flat[c * N + i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {  // reverse mode through the converters, one pixel at a time
+    Px s1{sig[1][0][i], sig[1][1][i], sig[1][2][i]}, s2{sig[2][0][i], sig[2][1][i], sig[2][2][i]};
+    Px g_res{gout.c0[i], gout.c1[i], gout.c2[i]};
+    if (!residual_only) {  // generate_image: clamp(img + residual, 0, 1)
+      Px y1 = lab2rgb(s1), y2 = hsv2rgb(s2);
+      float r0 = 2.0f * (sig[0][0][i] - 0.5f) + 2.0f * (y1.c0 - 0.5f) + 2.0f * (y2.c0 - 0.5f);
+      float r1 = 2.0f * (sig[0][1][i] - 0.5f) + 2.0f * (y1.c1 - 0.5f) + 2.0f * (y2.c1 - 0.5f);
+      float r2 = 2.0f * (sig[0][2][i] - 0.5f) + 2.0f * (y1.c2 - 0.5f) + 2.0f * (y2.c2 - 0.5f);
+      g_res = Px{g_res.c0 * pass01(in.c0[i] + r0), g_res.c1 * pass01(in.c1[i] + r1), g_res.c2 * pass01(in.c2[i] + r2)};
+    }
+    Px gy{2.0f * g_res.c0, 2.0f * g_res.c1, 2.0f * g_res.c2};
+    Px gs[3] = {gy, lab2rgb_bwd(s1, gy), hsv2rgb_bwd(s2, gy)};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      gP[s][0][i] = gs[s].c0 * sig[s][0][i] * (1.0f - sig[s][0][i]);
+      gP[s][1][i] = gs[s].c1 * sig[s][1][i] * (1.0f - sig[s][1][i]);
+      gP[s][2][i] = gs[s].c2 * sig[s][2][i] * (1.0f - sig[s][2][i]);
+    }
+  }
+}
+
 template <int V, bool SEQ>
 CURL_HD void trispace_bwd_px(Px in, float xw, float yh, const float* coef, Px gout, bool residual_only,
                              float (&vars)[3][3], float (&gP)[3][3]) {
-  constexpr int NC = PolyEval<V>::kCoeffs;
-  Px sp[3] = {in, rgb2lab(in), rgb2hsv(in)};
-  float sig[3][3];
+  PxN<1> i1{{in.c0}, {in.c1}, {in.c2}}, g1{{gout.c0}, {gout.c1}, {gout.c2}};
+  float x1[1] = {xw}, y1[1] = {yh}, v[3][3][1], g[3][3][1];
+  trispace_bwd_n<V, 1, SEQ>(i1, x1, y1, coef, g1, residual_only, v, g);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    vars[s][0] = sp[s].c0, vars[s][1] = sp[s].c1, vars[s][2] = sp[s].c2;
-    float v[V][1], o[3][1];
-    v[0][0] = sp[s].c0, v[1][0] = sp[s].c1, v[2][0] = sp[s].c2;
-    if (V == 5) v[V - 2][0] = xw, v[V - 1][0] = yh;
-    poly3_n<V, 1, SEQ>(o, v, coef + s * 3 * NC);
-    float flat[3] = {o[0][0], o[1][0], o[2][0]};
-    sigmoid_run(flat);
-    sig[s][0] = flat[0], sig[s][1] = flat[1], sig[s][2] = flat[2];
-  }
-  Px y1 = lab2rgb(Px{sig[1][0], sig[1][1], sig[1][2]}), y2 = hsv2rgb(Px{sig[2][0], sig[2][1], sig[2][2]});
-  float res[3] = {2.0f * (sig[0][0] - 0.5f) + 2.0f * (y1.c0 - 0.5f) + 2.0f * (y2.c0 - 0.5f),
-                  2.0f * (sig[0][1] - 0.5f) + 2.0f * (y1.c1 - 0.5f) + 2.0f * (y2.c1 - 0.5f),
-                  2.0f * (sig[0][2] - 0.5f) + 2.0f * (y1.c2 - 0.5f) + 2.0f * (y2.c2 - 0.5f)};
-  Px g_res = gout;
-  if (!residual_only)  // generate_image: clamp(img + residual, 0, 1)
-    g_res = Px{gout.c0 * pass01(in.c0 + res[0]), gout.c1 * pass01(in.c1 + res[1]), gout.c2 * pass01(in.c2 + res[2])};
-  Px gy{2.0f * g_res.c0, 2.0f * g_res.c1, 2.0f * g_res.c2};
-  Px gs[3] = {gy, lab2rgb_bwd(Px{sig[1][0], sig[1][1], sig[1][2]}, gy), hsv2rgb_bwd(Px{sig[2][0], sig[2][1], sig[2][2]}, gy)};
+  for (int s = 0; s < 3; ++s)
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    gP[s][0] = gs[s].c0 * sig[s][0] * (1.0f - sig[s][0]);
-    gP[s][1] = gs[s].c1 * sig[s][1] * (1.0f - sig[s][1]);
-    gP[s][2] = gs[s].c2 * sig[s][2] * (1.0f - sig[s][2]);
-  }
+    for (int c = 0; c < 3; ++c) vars[s][c] = v[s][c][0], gP[s][c] = g[s][c][0];
 }
 
 // acc[o][j] += gP[o] * m_{C*chunk + j}(v) for one pixel and one chunk of the monomials

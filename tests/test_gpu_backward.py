@@ -109,7 +109,7 @@ def test_train_step_gcurlnet(dev):
         loss.backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.backbone.classifier.parameters())
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
 
 
@@ -194,8 +194,8 @@ def test_trispace_regnet_train_step(dev):
     assert got, "no parameter received a gradient"
     net.zero_grad()
     R, L, H = net.generate_coefficients(img, mask)
-    ref_out = O.generate_image(img, O.trispace_residual(img, R, L, H))  # torch-eager on the device, autograd
-    ((ref_out - tgt) ** 2).mean().backward()
+    ref_out = O.generate_image(img.cpu(), O.trispace_residual(img.cpu(), R.cpu(), L.cpu(), H.cpu()))  # autograd
+    ((ref_out - tgt.cpu()) ** 2).mean().backward()
     worst = 0.0
     for k, p in net.named_parameters():
         if p.grad is not None and float(p.grad.abs().max()) > 0:

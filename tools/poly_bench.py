@@ -29,3 +29,21 @@ for name, c in (("trispace spatial (126)", c126), ("trispace non-spatial (35)", 
         ms = e0.elapsed_time(e1) / n
         print(f"{name:28s} {'VALU-only' if nomem else 'full     '} {ms*1e3:8.1f} us  {B*H*W/ms/1e6:7.1f} Gpix/s  "
               f"{B*H*W*24/ms/1e6:7.0f} GB/s algorithmic")
+
+# backward (coefficient gradients): the training shape (main.py crops) and the full-frame batch
+for (b, h, w) in ((32, 256, 256), (8, 1000, 1500)):
+    img = torch.rand(b, 3, h, w, device=dev)
+    g = torch.randn(b, 3, h, w, device=dev)
+    for name, c in (("trispace bwd (126)", c126[:b]), ("trispace bwd (35)", c35[:b])):
+        for i in range(3):
+            ops.trispace_backward(img, c, g)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 10
+        for i in range(n):
+            ops.trispace_backward(img, c, g)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print(f"{name:20s} {b}x{h}x{w}  {ms*1e3:9.1f} us  {b*h*w/ms/1e6:7.2f} Gpix/s")
