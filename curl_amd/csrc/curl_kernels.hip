@@ -141,7 +141,12 @@ struct StreamArgs {
   int no_mem;  // diagnostics: synthesise inputs, suppress stores (VALU-only timing; results undefined)
   unsigned W, H;  // image size in pixels (ops that need pixel coordinates)
   int op_flag;    // op-specific (trispace: residual only)
+  const uint8_t* white;  // FMT_U8HWC only: [B,H,W] 'L' mask of infer.py:39,46 (out*m + (1-m), m = L/255) or NULL
 };
+// pixel formats at the kernel's edges: planar float32 NCHW (what the reference's tensors are), or the file edge's
+// interleaved bytes (PIL HWC uint8 in, to_pil_image / astype('uint8') out) converted in registers
+#define FMT_F32CHW 0
+#define FMT_U8HWC 1
 
 template <int VEC>
 struct Pack;
@@ -174,6 +179,8 @@ __device__ __forceinline__ float lane(const v4f& v, int e) { return v[e]; }
 __device__ __forceinline__ float lane(const float& v, int) { return v; }
 __device__ __forceinline__ void set_lane(v4f& v, int e, float x) { v[e] = x; }
 __device__ __forceinline__ void set_lane(float& v, int, float x) { v = x; }
+__device__ __forceinline__ unsigned char lane_b(const v4b& v, int e) { return v[e]; }
+__device__ __forceinline__ unsigned char lane_b(const unsigned char& v, int) { return v; }
 __device__ __forceinline__ float mlane(const v4b& v, int e) { return v[e] ? 1.0f : 0.0f; }
 __device__ __forceinline__ float mlane(const unsigned char& v, int) { return v ? 1.0f : 0.0f; }
 
@@ -190,13 +197,59 @@ struct Tile {
   typename Pack<VEC>::T x0[U], x1[U], x2[U];
   typename Pack<VEC>::T mf[MK == CURL_MASK_F32 ? U : 1];
   typename Pack<VEC>::M mb[MK == CURL_MASK_U8 ? U : 1];
+  typename Pack<VEC>::M wm[U];  // FMT_U8HWC: white-background mask bytes
 };
 
-template <int VEC, int U, int MK, bool NT>
+// a*b rounded, then + c rounded -- what two eager ops produce (HIP's __fmul_rn/__fadd_rn are plain operators and
+// get contracted into one fma; the pragma is what hipcc's default fast-honor-pragmas mode respects)
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+  float t = a * b;
+  return t + c;
+}
+__device__ __forceinline__ float byte_of(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
+// 4 interleaved RGB pixels = 3 dwords [R0 G0 B0 R1][G1 B1 R2 G2][B2 R3 G3 B3] -> three planes of 4 floats in [0,1]
+__device__ __forceinline__ void unpack_rgb4(unsigned w0, unsigned w1, unsigned w2, v4f& r, v4f& g, v4f& b) {
+  r = v4f{byte_of(w0, 0), byte_of(w0, 3), byte_of(w1, 2), byte_of(w2, 1)};
+  g = v4f{byte_of(w0, 1), byte_of(w1, 0), byte_of(w1, 3), byte_of(w2, 2)};
+  b = v4f{byte_of(w0, 2), byte_of(w1, 1), byte_of(w2, 0), byte_of(w2, 3)};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = u8_to_unit(r[e]), g[e] = u8_to_unit(g[e]), b[e] = u8_to_unit(b[e]);
+}
+
+template <int VEC, int U, int MK, bool NT, int FMT>
 __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs& a, const typename Pack<VEC>::T* p0,
                                           size_t plane, size_t mask_off, unsigned base) {
   typedef typename Pack<VEC>::T T;
   typedef typename Pack<VEC>::M M;
+  if constexpr (FMT == FMT_U8HWC) {
+    // p0 = this image's interleaved bytes.  All loads first (raw words), conversions after.
+    unsigned raw[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      unsigned i = min(base + u * 256u, a.n - 1u);
+      if constexpr (VEC == 4) {
+        const unsigned* w = reinterpret_cast<const unsigned*>(p0) + 3 * (size_t)i;  // 12 bytes per lane, contiguous
+        raw[u][0] = ld<NT>(w), raw[u][1] = ld<NT>(w + 1), raw[u][2] = ld<NT>(w + 2);
+      } else {
+        const uint8_t* w = reinterpret_cast<const uint8_t*>(p0) + 3 * (size_t)i;
+        raw[u][0] = w[0], raw[u][1] = w[1], raw[u][2] = w[2];
+      }
+      if (MK == CURL_MASK_U8) t.mb[u] = ld<NT>(reinterpret_cast<const M*>(a.mask) + mask_off + i);
+      if (MK == CURL_MASK_F32) t.mf[u] = ld<NT>(reinterpret_cast<const T*>(a.mask) + mask_off + i);
+      if (a.white) t.wm[u] = ld<NT>(reinterpret_cast<const M*>(a.white) + mask_off + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (VEC == 4) {
+        unpack_rgb4(raw[u][0], raw[u][1], raw[u][2], t.x0[u], t.x1[u], t.x2[u]);
+      } else {
+        t.x0[u] = u8_to_unit((float)raw[u][0]), t.x1[u] = u8_to_unit((float)raw[u][1]);
+        t.x2[u] = u8_to_unit((float)raw[u][2]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     unsigned i = min(base + u * 256u, a.n - 1u);
@@ -217,7 +270,7 @@ __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs&
   }
 }
 
-template <class Op, int VEC, int U, int MK, bool NT>
+template <class Op, int VEC, int U, int MK, bool NT, int FMT>
 __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const StreamArgs& a,
                                               typename Pack<VEC>::T* q0, size_t plane, unsigned base,
                                               const typename Op::K& k) {
@@ -282,7 +335,32 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
       for (int e = 0; e < VEC; ++e) chk += lane(y0, e) + lane(y1, e) + lane(y2, e);
       keep = (chk == -123.0f);
     }
-    if (i < a.n && keep) {
+    if constexpr (FMT == FMT_U8HWC) {
+      unsigned q[3][VEC];  // [channel][pixel]
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float c[3] = {lane(y0, e), lane(y1, e), lane(y2, e)};
+        if (a.white) {  // infer.py:46: out*m + (1-m), two roundings like the eager ops (no contraction)
+          float m = u8_to_unit((float)lane_b(t.wm[u], e));
+          float one_minus = 1.0f - m;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) c[ch] = mul_then_add(c[ch], m, one_minus);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) q[ch][e] = unit_to_u8(c[ch]);
+      }
+      if (i < a.n) {
+        if constexpr (VEC == 4) {
+          unsigned* w = reinterpret_cast<unsigned*>(q0) + 3 * (size_t)i;
+          st<NT>(w, q[0][0] | (q[1][0] << 8) | (q[2][0] << 16) | (q[0][1] << 24));
+          st<NT>(w + 1, q[1][1] | (q[2][1] << 8) | (q[0][2] << 16) | (q[1][2] << 24));
+          st<NT>(w + 2, q[2][2] | (q[0][3] << 8) | (q[1][3] << 16) | (q[2][3] << 24));
+        } else {
+          uint8_t* w = reinterpret_cast<uint8_t*>(q0) + 3 * (size_t)i;
+          w[0] = (uint8_t)q[0][0], w[1] = (uint8_t)q[1][0], w[2] = (uint8_t)q[2][0];
+        }
+      }
+    } else if (i < a.n && keep) {
       st<NT>(q0 + i, y0);
       st<NT>(q0 + plane + i, y1);
       st<NT>(q0 + 2 * plane + i, y2);
@@ -290,7 +368,7 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
   }
 }
 
-template <class Op, int VEC, int U, int MK, bool NT>
+template <class Op, int VEC, int U, int MK, bool NT, int FMT = FMT_F32CHW>
 __global__ __launch_bounds__(256, Op::kMinWavesPerSimd) void stream_kernel(StreamArgs a) {
   typedef typename Pack<VEC>::T T;
   // grid = (chunks per image, images): both indices are SGPRs, no division
@@ -308,13 +386,15 @@ __global__ __launch_bounds__(256, Op::kMinWavesPerSimd) void stream_kernel(Strea
   }
   const typename Op::K k = Op::load(table, a);
   const size_t plane = (size_t)a.n;
-  const T* p0 = reinterpret_cast<const T*>(a.in) + (size_t)img * 3 * plane;
-  T* q0 = reinterpret_cast<T*>(a.out) + (size_t)img * 3 * plane;
+  // an image is 3 planes of `plane` vectors, or (FMT_U8HWC) plane*VEC pixels of 3 bytes = 3*plane*VEC bytes
+  const size_t image_bytes = (FMT == FMT_U8HWC) ? 3 * plane * VEC : 3 * plane * sizeof(T);
+  const T* p0 = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.in) + (size_t)img * image_bytes);
+  T* q0 = reinterpret_cast<T*>(reinterpret_cast<char*>(a.out) + (size_t)img * image_bytes);
   const size_t mask_off = (size_t)img * plane;
   const unsigned base = chunk * (256u * U) + threadIdx.x;
   Tile<VEC, U, MK> t;
-  load_tile<VEC, U, MK, NT>(t, a, p0, plane, mask_off, base);
-  compute_store<Op, VEC, U, MK, NT>(t, a, q0, plane, base, k);
+  load_tile<VEC, U, MK, NT, FMT>(t, a, p0, plane, mask_off, base);
+  compute_store<Op, VEC, U, MK, NT, FMT>(t, a, q0, plane, base, k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1046,10 +1126,9 @@ __global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* in,
   size_t b = i / HW, p = i - b * HW;
   const uint8_t* s = in + i * Cin;
   float* d = out + b * 3 * HW + p;
-  const float k = 255.0f;
-  d[0] = (float)s[0] / k;  // to_tensor: byte -> float, div(255)
-  d[HW] = (float)s[1] / k;
-  d[2 * HW] = (float)s[2] / k;
+  d[0] = u8_to_unit((float)s[0]);  // to_tensor: byte -> float, div(255)
+  d[HW] = u8_to_unit((float)s[1]);
+  d[2 * HW] = u8_to_unit((float)s[2]);
 }
 __global__ __launch_bounds__(256) void f32chw_to_u8hwc_kernel(const float* in, uint8_t* out, size_t HW,
                                                               size_t total) {
@@ -1183,6 +1262,7 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.W = (unsigned)W;
   a.H = (unsigned)H;
   a.op_flag = op_flag;
+  a.white = nullptr;
   hipError_t e;
   if constexpr (Op::kMask) {
     e = (mask_kind == CURL_MASK_U8)    ? launch_v<Op, CURL_MASK_U8>(g, a, s)
@@ -1190,6 +1270,58 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
                                        : launch_v<Op, CURL_MASK_NONE>(g, a, s);
   } else {
     e = launch_v<Op, CURL_MASK_NONE>(g, a, s);
+  }
+  if (e != hipSuccess) return hip_fail(e, name);
+  return 0;
+}
+
+// FMT_U8HWC launch: interleaved bytes in and out, optional white-background mask; one tile shape per op
+template <class Op, int MK>
+static hipError_t launch_u8_v(const Geometry& g, const StreamArgs& a, hipStream_t s) {
+  dim3 grid(g.blocks_per_image, g.n_images), block(256);
+  constexpr int U = Op::kSingleTileShape ? 1 : Op::kUnroll;
+  if (g.vec == 4)
+    hipLaunchKernelGGL((stream_kernel<Op, 4, U, MK, true, FMT_U8HWC>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((stream_kernel<Op, 1, U, MK, false, FMT_U8HWC>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+template <class Op>
+static int launch_stream_u8(const uint8_t* in, uint8_t* out, const void* mask, int mask_kind, const uint8_t* white,
+                            const float* coef, unsigned coef_stride, int B, int H, int W, hipStream_t s,
+                            const char* name, int op_flag = 0) {
+  Geometry g;
+  if (int rc = make_geometry(g, in, out, mask, mask_kind, B, H, W, 0, Op::kSingleTileShape ? 1 : Op::kUnroll)) return rc;
+  // make_geometry asks 16-byte alignment of in/out for the vector path; dword accesses need 4 (also for `white`)
+  size_t HW = (size_t)H * W;
+  bool aligned = (HW % 4 == 0) && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)white) % 4 == 0);
+  if (mask && mask_kind == CURL_MASK_F32 && ((uintptr_t)mask % 16)) aligned = false;
+  if (mask && mask_kind == CURL_MASK_U8 && ((uintptr_t)mask % 4)) aligned = false;
+  g.vec = aligned ? 4 : 1;
+  g.n = (unsigned)(HW / g.vec);
+  unsigned per_chunk = 256u * (unsigned)g.unroll;
+  g.blocks_per_image = (g.n + per_chunk - 1) / per_chunk;
+  StreamArgs a{};
+  a.in = reinterpret_cast<const float*>(in);
+  a.out = reinterpret_cast<float*>(out);
+  a.mask = mask;
+  a.white = white;
+  a.coef = coef;
+  a.coef_stride = coef_stride;
+  a.n = g.n;
+  a.blocks_per_image = g.blocks_per_image;
+  a.n_blocks = g.blocks_per_image * (unsigned)B;
+  a.no_mem = 0;
+  a.W = (unsigned)W;
+  a.H = (unsigned)H;
+  a.op_flag = op_flag;
+  hipError_t e;
+  if constexpr (Op::kMask) {
+    e = (mask_kind == CURL_MASK_U8)    ? launch_u8_v<Op, CURL_MASK_U8>(g, a, s)
+        : (mask_kind == CURL_MASK_F32) ? launch_u8_v<Op, CURL_MASK_F32>(g, a, s)
+                                       : launch_u8_v<Op, CURL_MASK_NONE>(g, a, s);
+  } else {
+    e = launch_u8_v<Op, CURL_MASK_NONE>(g, a, s);
   }
   if (e != hipSuccess) return hip_fail(e, name);
   return 0;
@@ -1433,6 +1565,28 @@ int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind, const 
                                 "curl_layer");
 }
 
+int curl_layer_fwd_u8hwc(const uint8_t* img, const void* mask, int mask_kind, const float* rawL, const float* rawR,
+                         const float* rawH, const uint8_t* white_mask, uint8_t* out, float* reg, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int Kl, int Kr, int Kh, unsigned flags,
+                         curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!rawL || !rawR || !rawH) return fail(CURL_E_NULL, "rawL/rawR/rawH must all be non-NULL");
+  if (int rc = check_mask(mask, mask_kind)) return rc;
+  if (int rc = check_K(Kl)) return rc;
+  if (int rc = check_K(Kr)) return rc;
+  if (int rc = check_K(Kh)) return rc;
+  if (flags) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point");
+  int n_knots = 3 * Kl + 3 * Kr + 4 * Kh;
+  if (int rc = check_ws(workspace, workspace_bytes, B, n_knots)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  unsigned stride = ws_stride(n_knots);
+  if (int rc = run_prep(rawL, 3, Kl, rawR, 3, Kr, rawH, 4, Kh, ws, stride, reg, B, s)) return rc;
+  return launch_stream_u8<OpLayer>(img, out, mask_kind ? mask : nullptr, mask_kind, white_mask, ws, stride, B, H, W, s,
+                                   "curl_layer_u8hwc");
+}
+
 size_t curl_layer_bwd_scratch_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   size_t HW = (size_t)H * W;
@@ -1524,6 +1678,20 @@ int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int
   if (num_coeffs == 126)
     return launch_stream<OpTriSpace<5>>(img, out, nullptr, 0, coeffs, 9 * 126, B, H, W, flags, s, "trispace", ro);
   return launch_stream<OpTriSpace<3>>(img, out, nullptr, 0, coeffs, 9 * 35, B, H, W, flags, s, "trispace", ro);
+}
+
+int curl_trispace_fwd_u8hwc(const uint8_t* img, const float* coeffs, const uint8_t* white_mask, uint8_t* out, int B, int H,
+                            int W, int num_coeffs, unsigned flags, curl_stream_t stream) {
+  g_err[0] = 0;
+  if (int rc = check_img(img, out, B, H, W)) return rc;
+  if (!coeffs) return fail(CURL_E_NULL, "coeffs is NULL");
+  if (num_coeffs != 126 && num_coeffs != 35)
+    return fail(CURL_E_KNOTS, "num_coeffs must be 126 (degree 4, 5 variables) or 35 (degree 4, 3 variables)");
+  if (flags) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point (the byte output is an image)");
+  hipStream_t s = (hipStream_t)stream;
+  if (num_coeffs == 126)
+    return launch_stream_u8<OpTriSpace<5>>(img, out, nullptr, 0, white_mask, coeffs, 9 * 126, B, H, W, s, "trispace_u8hwc");
+  return launch_stream_u8<OpTriSpace<3>>(img, out, nullptr, 0, white_mask, coeffs, 9 * 35, B, H, W, s, "trispace_u8hwc");
 }
 
 int curl_poly_layer_f32(const float* img, const float* coeffs, float* out, int B, int H, int W, int num_variables,

@@ -57,6 +57,22 @@ CURL_HD float clampf(float x, float lo, float hi) {
 }
 CURL_HD float clamp01(float x) { return clampf(x, 0.0f, 1.0f); }
 
+// to_tensor's byte -> float: b / 255 correctly rounded, for b = 0..255 held exactly in a float, without the
+// ~10-instruction IEEE division: one Newton correction of b * fl(1/255) (all 256 values checked: test_twin_math).
+CURL_HD float u8_to_unit(float b) {
+  const float r = 1.0f / 255.0f;
+  float q = b * r;
+  float e = fmaf(-q, 255.0f, b);
+  return fmaf(e, r, q);
+}
+// (x * 255).astype('uint8') / to_pil_image's mul(255).byte(): truncation; out-of-range saturates
+CURL_HD unsigned unit_to_u8(float x) {
+  float v = x * 255.0f;
+  v = v < 0.0f ? 0.0f : v;   // also maps NaN to 0
+  v = v > 255.0f ? 255.0f : v;
+  return (unsigned)(int)v;
+}
+
 // ---------------------------------------------------------------- branch-free selects
 // Measured on MI355X (tools/ubench/valu_rate.hip): v_cndmask_b32 with its mask in VCC -- what hipcc emits
 // for `c ? a : b` -- issues once per ~23 cycles per SIMD, against 2 for v_fma/v_mul/v_add/shift/and/or and

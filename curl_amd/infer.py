@@ -44,19 +44,26 @@ def encoder_view(img, mask, size=320):
 
 @torch.no_grad()
 def enhance(net, img_u8, mask_u8, device):
-    """img_u8: HxWx3|4 uint8, mask_u8: HxW uint8 ('L').  Returns HxWx3 uint8 (numpy)."""
-    x = ops.u8hwc_to_f32chw(torch.from_numpy(np.array(img_u8)).to(device)[None])
-    tmask = torch.from_numpy(np.array(mask_u8)).to(device)[None, None].float() / 255.0  # to_tensor
+    """img_u8: HxWx3|4 uint8, mask_u8: HxW uint8 ('L').  Returns HxWx3 uint8 (numpy).
+    The full-resolution pass runs on the file's own bytes (ops.*_u8hwc: byte/255, the model's per-pixel part, the
+    white background and the truncating *255 in one launch); only the 320x320 encoder view is made in float."""
+    rgb = torch.from_numpy(np.ascontiguousarray(np.asarray(img_u8)[..., :3])).to(device)[None]  # alpha dropped
+    white = torch.from_numpy(np.array(mask_u8, dtype=np.uint8)).to(device)[None]
+    x = ops.u8hwc_to_f32chw(rgb)
+    tmask = white[:, None].float() / 255.0  # to_tensor
     small, msmall = encoder_view(x, tmask)
+    del x
     if isinstance(net, model_mod.TriSpaceRegNet):
-        residual = net(small, msmall, x)                        # infer.py:44 (is_train=False -> residual)
-        out = net.generate_image(x, residual)                   # infer.py:45
-        return ops.compose_white_u8hwc(out, tmask)[0].cpu().numpy()  # infer.py:46-47
+        coeffs = torch.stack(net.generate_coefficients(small, msmall), 1)       # infer.py:44, model.py:522-527
+        return ops.trispace_forward_u8hwc(rgb, coeffs, white)[0].cpu().numpy()  # infer.py:44-47
     knots = net.predict_knots(small * msmall)  # the encoder sees the masked 320x320 view
     L, R, H = knots[:, :net.curve_break_1], knots[:, net.curve_break_1:net.curve_break_2], knots[:, net.curve_break_2:]
-    full_mask = torch.ones_like(tmask)  # the reference applies the mask only when compositing (infer.py:44-46)
-    out, _ = net.curllayer(x, full_mask, L, R, H)
-    return ops.compose_white_u8hwc(out, tmask)[0].cpu().numpy()
+    # the reference applies the mask only when compositing (infer.py:44-46): no layer mask
+    cl = net.curllayer
+    out, _ = ops.curl_layer_forward_u8hwc(rgb, None, L[:, :cl.num_lab_points].contiguous(),
+                                          R[:, :cl.num_rgb_points].contiguous(),
+                                          H[:, :cl.num_hsv_points].contiguous(), white)
+    return out[0].cpu().numpy()
 
 
 def infer(argv=None):

@@ -3,6 +3,8 @@
 PyTorch is plumbing here: it owns device memory (caching allocator) and the stream.
 Every function enqueues on torch's CURRENT stream and returns without synchronising.
 """
+from types import SimpleNamespace
+
 import torch
 
 from . import _lib
@@ -327,6 +329,62 @@ def compose_white_u8hwc(x, mask):
     _lib.check(lib.curl_compose_white_u8hwc(x.data_ptr(), m.data_ptr(), kind, out.data_ptr(), B, H, W, _stream(x)),
                "curl_compose_white_u8hwc")
     return out[0] if squeeze else out
+
+
+def _bytes_image(x, name="img"):
+    _need_device(x, name)
+    if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError(f"{name} must be uint8 [B,H,W,3] (PIL's RGB layout), got {x.dtype} {tuple(x.shape)}")
+    return x.contiguous()
+
+
+def _white(white_mask, img_u8):
+    if white_mask is None:
+        return None
+    _need_device(white_mask, "white_mask")
+    B, H, W, _ = img_u8.shape
+    if white_mask.dtype != torch.uint8 or tuple(white_mask.shape) != (B, H, W):
+        raise ValueError(f"white_mask must be uint8 [B,H,W] ('L' image), got {white_mask.dtype} {tuple(white_mask.shape)}")
+    return white_mask.contiguous()
+
+
+def trispace_forward_u8hwc(img_u8, coeffs, white_mask=None):
+    """infer.py:35-47 on the file's own bytes, one launch: byte/255 -> generate_residual + generate_image ->
+    [out*m + (1-m), m = white_mask/255] -> truncating *255.  img_u8 [B,H,W,3] uint8 -> [B,H,W,3] uint8."""
+    lib = _lib.load()
+    x = _bytes_image(img_u8)
+    B, H, W, _ = x.shape
+    _need_device(coeffs, "coeffs")
+    if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
+        raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
+    c = coeffs.to(torch.float32).contiguous()
+    wm = _white(white_mask, x)
+    out = torch.empty_like(x)
+    rc = lib.curl_trispace_fwd_u8hwc(x.data_ptr(), c.data_ptr(), _ptr(wm), out.data_ptr(), B, H, W, c.shape[3], 0,
+                                     _stream(x))
+    _lib.check(rc, "curl_trispace_fwd_u8hwc")
+    return out
+
+
+def curl_layer_forward_u8hwc(img_u8, mask, L, R, H, white_mask=None):
+    """CURLLayer.forward between byte images: byte/255 -> the layer (mask [B,1,H,W] as in curl_layer_forward) ->
+    [white background] -> truncating *255.  -> (uint8 [B,H,W,3], reg [B])."""
+    lib = _lib.load()
+    x = _bytes_image(img_u8)
+    B, Hh, W, _ = x.shape
+    Lc, Kl = _knots(L, "L", 3, B)
+    Rc, Kr = _knots(R, "R", 3, B)
+    Hc, Kh = _knots(H, "H", 4, B)
+    m, kind = _mask(mask, SimpleNamespace(shape=(B, 3, Hh, W)))
+    wm = _white(white_mask, x)
+    out = torch.empty_like(x)
+    reg = torch.empty(B, dtype=torch.float32, device=x.device)
+    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, x.device)
+    rc = lib.curl_layer_fwd_u8hwc(x.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(), _ptr(wm),
+                                  out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, Kl, Kr, Kh, 0,
+                                  _stream(x))
+    _lib.check(rc, "curl_layer_fwd_u8hwc")
+    return out, reg
 
 
 def psnr_per_image(a, b, mask=None, max_intensity=1.0):

@@ -146,6 +146,21 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind,
 int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
                           int num_coeffs, unsigned flags, curl_stream_t stream);
 
+/* replaces: the file-to-file inference path of infer.py:35-47 in ONE launch -- TF.to_tensor (byte/255), the
+ *           full-resolution generate_residual + generate_image, `out*tmask + (1-tmask)` and to_pil_image's
+ *           mul(255).byte() -- on interleaved bytes: 6 B/px instead of 15 + 24 + 16 through the f32 entry points.
+ * img, out: [B,H,W,3] uint8 (PIL's RGB layout).  white_mask: [B,H,W] uint8 ('L' image, m = byte/255) or NULL
+ * (no compositing).  flags must be 0 (the byte output is the image, never the residual). */
+int curl_trispace_fwd_u8hwc(const uint8_t* img, const float* coeffs, const uint8_t* white_mask, uint8_t* out,
+                            int B, int H, int W, int num_coeffs, unsigned flags, curl_stream_t stream);
+
+/* Same file-edge fusion for the curve layer (CURLLayer.forward between evaluate.py:64-66-style byte images):
+ * byte/255 -> curl_layer_fwd_f32 semantics (mask, knots, reg as there) -> [white background] -> truncating *255. */
+int curl_layer_fwd_u8hwc(const uint8_t* img, const void* mask, int mask_kind, const float* rawL, const float* rawR,
+                         const float* rawH, const uint8_t* white_mask, uint8_t* out, float* reg, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int Kl, int Kr, int Kh, unsigned flags,
+                         curl_stream_t stream);
+
 /* replaces: autograd of curl_trispace_fwd_f32 w.r.t. the coefficients (what loss.backward() runs through
  *           TriSpaceRegNet.generate_residual, main.py:287) -- the image is data, its gradient is not produced.
  * grad_out [B,3,H,W] -> grad_coeffs [B,3,3,num_coeffs] (ASSIGNED).  flags: CURL_F_RESIDUAL_ONLY as in the forward.

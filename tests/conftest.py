@@ -161,6 +161,14 @@ def twin():
             lib.twin_trispace_bwd(P(img), P(coeffs), P(gout), P(g), B, Hh, W, V, int(residual_only))
             return g
 
+        @staticmethod
+        def u8_edges(x):
+            x = f32(x).ravel()
+            unit = np.empty(256, np.float32)
+            q = np.empty(x.size, np.uint8)
+            lib.twin_u8_edges(P(unit), P(x), q.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(x.size))
+            return unit, q
+
     return Twin
 
 

@@ -544,3 +544,83 @@ def test_hip_graph_capture_and_replay(ops, dev, golden):
         torch.cuda.synchronize()
         assert max_err(N(static_out), c[f"s01_{name}_ones_out"]) <= 1e-5
         np.testing.assert_allclose(N(static_reg), c[f"s01_{name}_ones_reg"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 36, 52), (1, 33, 65), (2, 7, 9)])
+@pytest.mark.parametrize("nc", [126, 35])
+def test_trispace_u8hwc_fused_file_edge(ops, dev, shape, nc):
+    """infer.py:35-47 in one launch on interleaved bytes == the same steps through the f32 entry points
+    (ingest, trispace, white background, truncating egress), byte for byte; and within one grey level of the
+    oracle's chain (truncation edges) on < 1 % of the bytes.  Shapes cover the dword path and the byte path."""
+    import curl_oracle as O
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W + nc)
+    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g)
+    white = torch.randint(0, 256, (B, H, W), dtype=torch.uint8, generator=g)
+    white[:, : H // 3] = 0
+    white[:, -H // 3:] = 255
+    coeffs = torch.randn(B, 3, 3, nc, generator=g) * 0.2
+    for wm in (None, white):
+        got = ops.trispace_forward_u8hwc(img.to(dev), coeffs.to(dev), None if wm is None else wm.to(dev))
+        x = ops.u8hwc_to_f32chw(img.to(dev))
+        y = ops.trispace_forward(x, coeffs.to(dev))
+        if wm is not None:
+            m = (wm.float() / 255).unsqueeze(1).to(dev)  # divided on the CPU: torch's GPU div-by-scalar multiplies by 1/255
+            y = y * m + (1 - m)
+        steps = ops.f32chw_to_u8hwc(y)
+        assert torch.equal(got, steps)
+        xo = torch.stack([O.u8hwc_to_f32chw(img[b].numpy()) for b in range(B)])
+        ro = O.trispace_residual(xo, coeffs[:, 0], coeffs[:, 1], coeffs[:, 2], spatial=(nc == 126))
+        yo = O.generate_image(xo, ro)
+        if wm is not None:
+            yo = O.white_background(yo, (wm.float() / 255).unsqueeze(1))
+        want = np.stack([O.f32chw_to_u8hwc(yo[b]) for b in range(B)])
+        d = np.abs(N(got).astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+@pytest.mark.parametrize("shape,mask_kind", [((2, 36, 52), "bool"), ((1, 33, 65), "f32"), ((2, 7, 9), None),
+                                             ((1, 40, 64), None)])
+def test_curl_layer_u8hwc_fused_file_edge(ops, dev, shape, mask_kind):
+    import curl_oracle as O
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g)
+    white = torch.randint(0, 256, (B, H, W), dtype=torch.uint8, generator=g)
+    L, R = torch.randn(B, 48, generator=g) * 0.1, torch.randn(B, 48, generator=g) * 0.1
+    Hk = torch.randn(B, 64, generator=g) * 0.1
+    mask = None
+    if mask_kind == "bool":
+        mask = torch.rand(B, 1, H, W, generator=g) > 0.3
+    elif mask_kind == "f32":
+        mask = torch.rand(B, 1, H, W, generator=g)
+    md = None if mask is None else mask.to(dev)
+    for wm in (None, white):
+        got, reg = ops.curl_layer_forward_u8hwc(img.to(dev), md, L.to(dev), R.to(dev), Hk.to(dev),
+                                                None if wm is None else wm.to(dev))
+        x = ops.u8hwc_to_f32chw(img.to(dev))
+        y, reg2 = ops.curl_layer_forward(x, md, L.to(dev), R.to(dev), Hk.to(dev))
+        if wm is not None:
+            m = (wm.float() / 255).unsqueeze(1).to(dev)
+            y = y * m + (1 - m)
+        assert torch.equal(got, ops.f32chw_to_u8hwc(y))
+        assert torch.equal(reg, reg2)
+        xo = torch.stack([O.u8hwc_to_f32chw(img[b].numpy()) for b in range(B)])
+        mo = torch.ones(B, 1, H, W) if mask is None else mask.float()
+        yo, _ = O.curl_layer(xo, mo, L, R, Hk)
+        if wm is not None:
+            yo = O.white_background(yo, (wm.float() / 255).unsqueeze(1))
+        want = np.stack([O.f32chw_to_u8hwc(yo[b]) for b in range(B)])
+        d = np.abs(N(got).astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def test_u8hwc_entry_points_reject_bad_arguments(ops, dev):
+    img = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=dev)
+    c = torch.zeros(1, 3, 3, 126, device=dev)
+    with pytest.raises(ValueError):
+        ops.trispace_forward_u8hwc(img.float(), c)
+    with pytest.raises(ValueError):
+        ops.trispace_forward_u8hwc(img, c, torch.zeros(1, 8, 9, dtype=torch.uint8, device=dev))
+    with pytest.raises(RuntimeError):
+        ops.trispace_forward_u8hwc(img.cpu(), c)

@@ -129,3 +129,17 @@ def test_reference_sum_order_depends_on_shape(twin):
         if must_match:
             assert np.array_equal(out, ref), shape
         assert max_err(out, ref) <= 1e-6, shape
+
+
+def test_file_edge_scalars(twin):
+    """u8_to_unit is to_tensor's byte/255 for every byte (a Newton-corrected multiply, no division), and
+    unit_to_u8 is (x*255).astype('uint8') on [0,1] (evaluate.py:64), saturating outside."""
+    g = np.random.default_rng(0)
+    x = np.concatenate([g.random(4096, dtype=np.float32), np.arange(256, dtype=np.float32) / np.float32(255),
+                        np.array([0.0, 1.0, -0.3, 1.7, 0.99999994], np.float32)])
+    unit, q = twin.u8_edges(x)
+    want = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255).numpy()
+    assert np.array_equal(unit, want)
+    inside = (x >= 0) & (x <= 1)
+    assert np.array_equal(q[inside], (x[inside] * np.float32(255)).astype(np.uint8))
+    assert q[-3] == 0 and q[-2] == 255

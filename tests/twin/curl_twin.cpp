@@ -290,4 +290,10 @@ int twin_trispace_bwd(const float* img, const float* coeffs, const float* gout, 
   else trispace_bwd_host<3>(img, coeffs, gout, gcoef, B, H, W, residual_only);
   return 0;
 }
+// file-edge scalars: out[b] = u8_to_unit(b) for b = 0..255; q[i] = unit_to_u8(x[i])
+int twin_u8_edges(float* unit256, const float* x, unsigned char* q, long n) {
+  for (int b = 0; b < 256; ++b) unit256[b] = curlm::u8_to_unit((float)b);
+  for (long i = 0; i < n; ++i) q[i] = (unsigned char)curlm::unit_to_u8(x[i]);
+  return 0;
+}
 }
