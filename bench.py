@@ -43,7 +43,8 @@ def make_inputs(B, device, seed, n_sets=2):
         R = (torch.randn(B, 48, generator=g) * 0.1).to(device)
         Hk = (torch.randn(B, 64, generator=g) * 0.1).to(device)
         poly = (torch.randn(B, 3, 3, 126, generator=g) * 0.2).to(device)
-        sets.append((img, L, R, Hk, poly))
+        u8 = (img * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()  # the file edge's interleaved bytes
+        sets.append((img, L, R, Hk, poly, u8))
     return sets
 
 
@@ -58,6 +59,10 @@ WORKLOADS = {
     "rgb_only": ("RGB-only 3 curves (adjust_rgb, BASELINE configs[1]), no mask", 24.0, "OpAdjust3", None),
     "trispace": ("TriSpaceRegNet per-pixel path (SURVEY 8f-1): 3 x degree-4 polynomial layers (126 coeffs x 3 outputs) in "
                  "RGB/Lab/HSV + converters + clamp, fused; arithmetic-bound (~2.6 kFLOP/px)", 24.0, "OpTriSpace", None),
+    "layer_u8": ("CURLLayer.forward on interleaved uint8 HWC in and out (SURVEY 8f-2: byte/255 and truncating *255 "
+                 "fused), bool mask all ones", 7.0, "OpLayer", "ones"),
+    "trispace_u8": ("TriSpaceRegNet per-pixel path on interleaved uint8 HWC in and out (infer.py:35-47 fused)", 6.0,
+                    "OpTriSpace", None),
 }
 
 
@@ -71,6 +76,10 @@ def make_step(name, ops, masks):
         return lambda s: ops.adjust_rgb(s[0], s[2])
     if name == "trispace":
         return lambda s: ops.trispace_forward(s[0], s[4])
+    if name == "layer_u8":
+        return lambda s: ops.curl_layer_forward_u8hwc(s[5], mask, s[1], s[2], s[3])
+    if name == "trispace_u8":
+        return lambda s: ops.trispace_forward_u8hwc(s[5], s[4])
     raise ValueError(name)
 
 
