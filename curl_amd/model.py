@@ -7,7 +7,7 @@ the encoder of GCURLNet is stock PyTorch-ROCm convolutions, as BASELINE.json's n
 import torch
 import torch.nn as nn
 
-from . import colors, ops
+from . import colors, metric, ops
 
 
 class _CurlLayerFn(torch.autograd.Function):
@@ -329,15 +329,16 @@ class _LossTermsFn(torch.autograd.Function):
 
 
 class CURLLoss(nn.Module):
-    """model.py:35-118.  `msssim_layer(L_pred, L_target)` supplies the MS-SSIM of model.py:103-105 (the
-    reference's MSSSIMMetric is grouped convolutions, metric.py:75-211; it is not rebuilt here and its
-    constructor cannot run without a GPU, so that term is parity-unpinned); None leaves the term at zero."""
+    """model.py:35-118: the four pointwise terms on the fused HIP kernels, the MS-SSIM term of
+    model.py:103-105 through `metric.MSSSIMMetric(num_channel=num_channel)` exactly as the reference builds it
+    (model.py:48: default window 11; `ssim_window_size` is stored and, as there, not used)."""
 
-    def __init__(self, ssim_window_size=5, num_channel=1, msssim_layer=None):
+    def __init__(self, ssim_window_size=5, num_channel=1, msssim_layer="reference"):
         super().__init__()
         self.ssim_window_size = ssim_window_size
         self.num_channel = num_channel
-        self.msssim_layer = msssim_layer
+        # None switches the term off (kernel-only timing); anything callable replaces it
+        self.msssim_layer = metric.MSSSIMMetric(num_channel=num_channel) if msssim_layer == "reference" else msssim_layer
         self.rgb2lab = colors.RGB2LAB()
         self.rgb2hsv = colors.RGB2HSV()
 

@@ -442,3 +442,52 @@ def curl_loss(pred, target, mask, ssim_loss_value):
     """model.py:111-116 given the MS-SSIM loss term."""
     rgb, cosine, lab, hsv, _, _ = curl_loss_terms(pred, target, mask)
     return (rgb + cosine + lab + hsv + 10 * ssim_loss_value) / 5
+
+
+# ---------------------------------------------------------------- MS-SSIM (metric.py:75-211)
+def msssim_window(window_size, num_channel, sigma=1.5):
+    """MSSSIMMetric.create_window / gaussian (metric.py:90-118): normalised Gaussian, outer product,
+    expanded to [C,1,ws,ws]."""
+    from math import exp
+    g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(num_channel, 1, window_size, window_size).contiguous()
+
+
+def ssim_and_cs(img1, img2, window):
+    """MSSSIMMetric.compute_ssim (metric.py:120-166): per-image mean SSIM and contrast-structure term."""
+    import torch.nn.functional as F
+    C, ws = window.shape[0], window.shape[-1]
+    window = window.type_as(img1)
+    conv = lambda x: F.conv2d(x, window, padding=ws // 2, groups=C)  # noqa: E731
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = conv(img1 * img1) - mu1_sq
+    sigma2_sq = conv(img2 * img2) - mu2_sq
+    sigma12 = conv(img1 * img2) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    cs = torch.mean((2.0 * sigma12 + C2) / (sigma1_sq + sigma2_sq + C2), dim=(1, 2, 3))
+    return ssim_map.mean(dim=(1, 2, 3)), cs
+
+
+def msssim(img1, img2, window_size=11, num_channel=3):
+    """MSSSIMMetric.compute_msssim (metric.py:168-208): 5 levels, 2x2 average pooling between them,
+    (x+1)/2 normalisation, prod(mcs[:-1]^w * ssim[-1]^w[-1])."""
+    import torch.nn.functional as F
+    weights = torch.tensor([0.0448, 0.2856, 0.3001, 0.2363, 0.1333], dtype=torch.float32)
+    if img1.shape[2] != img2.shape[2]:
+        img1 = img1.transpose(2, 3)
+    window = msssim_window(window_size, num_channel)
+    ssims, mcs = [], []
+    for _ in range(weights.numel()):
+        s, c = ssim_and_cs(img1, img2, window)
+        ssims.append(s)
+        mcs.append(c)
+        img1, img2 = F.avg_pool2d(img1, (2, 2)), F.avg_pool2d(img2, (2, 2))
+    ssims = (torch.stack(ssims, dim=1) + 1) / 2
+    mcs = (torch.stack(mcs, dim=1) + 1) / 2
+    w = weights.reshape(1, -1).to(img1.dtype)
+    pow1, pow2 = mcs ** w, ssims ** w
+    return torch.prod(pow1[:, :-1] * pow2[:, -1].reshape(-1, 1), dim=1)

@@ -1,6 +1,7 @@
 """CURLLoss pointwise terms (model.py:78-116): oracle and kernel arithmetic (host twin) vs golden values computed
 with the reference's colors.py and torch autograd."""
 import numpy as np
+import pytest
 import torch
 
 import curl_oracle as O
@@ -51,3 +52,36 @@ def test_twin_backward(twin, golden):
     d = np.abs(got - ref)
     scale = np.abs(ref).max()
     assert np.quantile(d, 0.995) <= 2e-4 * scale and d.max() <= 5e-2 * scale
+
+
+@pytest.mark.parametrize("tag", ["loss", "rgb", "w5"])
+def test_msssim_host_mirror_vs_reference_golden(golden, tag):
+    """curl_amd.metric.MSSSIMMetric (stock torch, separable window, no .cuda()) against outputs and gradients of
+    the reference's own class (tests/golden/make_golden_msssim.py).  Runs on the CPU: nothing here is HIP."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # load curl_amd/metric.py without importing the package's HIP loader side (ops is only used by PSNRMetric)
+    pkg = types.ModuleType("curl_amd_metric_only")
+    pkg.__path__ = [os.path.join(root, "curl_amd")]
+    sys.modules.setdefault("curl_amd_metric_only", pkg)
+    sys.modules.setdefault("curl_amd_metric_only.ops", types.ModuleType("curl_amd_metric_only.ops"))
+    spec = importlib.util.spec_from_file_location("curl_amd_metric_only.metric", os.path.join(root, "curl_amd", "metric.py"))
+    metric = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(metric)
+    g = golden("msssim")
+    ws, ch = (int(v) for v in g[tag + "_cfg"])
+    m = metric.MSSSIMMetric(window_size=ws, num_channel=ch)
+    assert np.abs(m.gaussian_window.numpy() - g[tag + "_window"]).max() <= 1e-8
+    assert list(m.state_dict().keys()) == ["msssim_weights"]  # what the reference's checkpoints hold for it
+    a = torch.from_numpy(g[tag + "_a"]).requires_grad_(True)
+    b = torch.from_numpy(g[tag + "_b"])
+    out = m(a, b)
+    assert np.abs(out.detach().numpy() - g[tag + "_out"]).max() <= 2e-6
+    s, c = m.compute_ssim(a.detach(), b)
+    assert np.abs(s.numpy() - g[tag + "_ssim"]).max() <= 2e-6 and np.abs(c.numpy() - g[tag + "_cs"]).max() <= 2e-6
+    (out * torch.from_numpy(g[tag + "_w"])).sum().backward()
+    ref = g[tag + "_grad_a"]
+    assert np.abs(a.grad.numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
