@@ -48,6 +48,13 @@ CURL_HD float rcp_refined(float x) {
   return 1.0f / x;
 #endif
 }
+CURL_HD float hw_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);  // v_rcp_f32, 1 ulp
+#else
+  return 1.0f / x;
+#endif
+}
 CURL_HD float clampf(float x, float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_fmed3f(x, lo, hi);  // v_med3_f32
@@ -352,14 +359,19 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 }
 
 // ---------------------------------------------------------------- RGB -> HSV   colors.py:195-242
-template <int N>
+// UNIT = the caller guarantees r, g, b in [0,1] (the curve layer: adjust3 has just clamped them) and consumes
+// h, s, v through adjust_hsv4, which clamps what it produces.  Then the 1e-9 floors of colors.py:205,240 are
+// six v_med3 per pixel that change the layer's output by < 1e-8 (they only move channels that are exactly 0 to
+// 1e-9: relative hue/saturation changes of 1e-9/max, scaled by v = max on the way back to RGB), and the
+// reciprocal needs no Newton step.
+template <int N, bool UNIT = false>
 CURL_HD void rgb2hsv_n(PxN<N>& p) {
   float r[N], g[N], b[N], mx[N], df[N], rdm[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    r[i] = clampf(p.c0[i], kHsvFloor, 1.0f);
-    g[i] = clampf(p.c1[i], kHsvFloor, 1.0f);
-    b[i] = clampf(p.c2[i], kHsvFloor, 1.0f);
+    r[i] = UNIT ? p.c0[i] : clampf(p.c0[i], kHsvFloor, 1.0f);
+    g[i] = UNIT ? p.c1[i] : clampf(p.c1[i], kHsvFloor, 1.0f);
+    b[i] = UNIT ? p.c2[i] : clampf(p.c2[i], kHsvFloor, 1.0f);
     mx[i] = fmaxf(r[i], fmaxf(g[i], b[i]));
     df[i] = mx[i] - fminf(r[i], fminf(g[i], b[i]));
     // 1/df and 1/mx from ONE reciprocal: q = 1/(df*mx), 1/df = q*mx, 1/mx = q*df (df*mx >= 1e-25, no underflow).
@@ -368,7 +380,7 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
   }
   CURL_FENCE();
 #pragma unroll
-  for (int i = 0; i < N; ++i) rdm[i] = rcp_refined(rdm[i]);
+  for (int i = 0; i < N; ++i) rdm[i] = UNIT ? hw_rcp(rdm[i]) : rcp_refined(rdm[i]);
   CURL_FENCE();
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -383,9 +395,9 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
     h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
     float s = keep_if(live, df[i] * (rdm[i] * df[i]));  // colors.py:234-237: df/mx (0 when df == 0)
-    p.c0[i] = clampf(h, kHsvFloor, 1.0f);  // colors.py:240
-    p.c1[i] = clampf(s, kHsvFloor, 1.0f);
-    p.c2[i] = clampf(mx[i], kHsvFloor, 1.0f);
+    p.c0[i] = UNIT ? h : clampf(h, kHsvFloor, 1.0f);  // colors.py:240
+    p.c1[i] = UNIT ? s : clampf(s, kHsvFloor, 1.0f);
+    p.c2[i] = UNIT ? mx[i] : clampf(mx[i], kHsvFloor, 1.0f);
   }
 }
 
@@ -411,10 +423,11 @@ CURL_HD float pow_inv_gamma(float x) { return hw_exp2(kInvGamma * hw_log2(x)); }
 CURL_HD float cbrt_pos(float x) { return hw_exp2(kThird * hw_log2(x)); }
 
 // ---------------------------------------------------------------- HSV -> RGB   colors.py:131-177
+template <bool UNIT = false>  // UNIT: h, s, v already in [0,1] (straight out of adjust_hsv4's clamps)
 CURL_HD Px hsv2rgb(Px p) {
   // colors.py:141-175 in sextant units: clamp(360h - a, 0, 60) * (d/60) == clamp(6h - a/60, 0, 1) * d,
   // so every ramp is one saturating add (v_add_f32 ... clamp) and the /60 disappears.
-  float h = clamp01(p.c0) * 6.0f, s = clamp01(p.c1), v = clamp01(p.c2);
+  float h = (UNIT ? p.c0 : clamp01(p.c0)) * 6.0f, s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
   float q = v * (1.0f - s);
   float d = v - q;
   // the reference's identically-zero terms (m1,m3,m5 = 0) add +0 and are dropped
@@ -458,9 +471,10 @@ CURL_HD Px adjust3(Px p, Affine k0, Affine k1, Affine k2) {
   return o;
 }
 // adjust_hsv (curves.py:41-87): H->H, H->S (on the ADJUSTED hue), S->S, V->V.
+template <bool UNIT = false>  // UNIT: s and v arrive in [0,1] (rgb2hsv_n<N, true>), their input clamp is the identity
 CURL_HD Px adjust_hsv4(Px p, Affine k0, Affine k1, Affine k2, Affine k3) {
   float h = clamp01(curve_mul(p.c0, p.c0, k0));
-  float s = clamp01(p.c1), v = clamp01(p.c2);
+  float s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
   s = clamp01(curve_mul(s, h, k1));
   s = clamp01(curve_mul(s, s, k2));
   v = clamp01(curve_mul(v, v, k3));
@@ -579,16 +593,17 @@ CURL_HD void curl_layer_n(PxN<N>& p, const float (&m)[N], const LayerCoef& k) {
     }
     p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
   }
-  rgb2hsv_n<N>(p);  // model.py:163
+  // a binary mask leaves the clamped RGB of adjust3 untouched: everything up to hsv2rgb stays in [0,1]
+  rgb2hsv_n<N, BINARY>(p);  // model.py:163
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    Px h = adjust_hsv4(Px{p.c0[i], p.c1[i], p.c2[i]}, k.hsv[0], k.hsv[1], k.hsv[2], k.hsv[3]);  // model.py:165
+    Px h = adjust_hsv4<BINARY>(Px{p.c0[i], p.c1[i], p.c2[i]}, k.hsv[0], k.hsv[1], k.hsv[2], k.hsv[3]);  // model.py:165
     if (!BINARY) {                                                                                 // model.py:166
       h.c0 *= m[i];
       h.c1 *= m[i];
       h.c2 *= m[i];
     }
-    Px res = hsv2rgb(h);                                   // model.py:169
+    Px res = hsv2rgb<BINARY>(h);                           // model.py:169
     p.c0[i] = clamp01(in.c0[i] + res.c0) * m[i];           // model.py:170
     p.c1[i] = clamp01(in.c1[i] + res.c1) * m[i];
     p.c2[i] = clamp01(in.c2[i] + res.c2) * m[i];

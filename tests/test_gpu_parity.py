@@ -125,9 +125,11 @@ def test_layer_golden_sigma05_conditioning(ops, dev, golden):
 
 
 # ------------------------------------------------------------------ mask kinds agree bit for bit
-def test_binary_mask_paths_are_bit_identical(ops, dev, golden):
+def test_binary_mask_paths_agree(ops, dev, golden):
     """bool / uint8 masks take the binary specialisation (dropped multiplies, masked-out shortcut);
-    a float mask holding the same 0/1 values takes the general path.  Same bits out."""
+    a float mask holding the same 0/1 values takes the general path.  Same bits out for the Lab stage and between
+    the two binary kinds; the layer's binary form also drops the 1e-9 floors inside its HSV stage (values there
+    are already in [0,1]), which moves results by < 3e-7."""
     c = golden("chain")
     L, R, H = (T(c["s01" + k], dev) for k in ("_L", "_R", "_H"))
     img = T(c["img"], dev)
@@ -138,12 +140,13 @@ def test_binary_mask_paths_are_bit_identical(ops, dev, golden):
         o_b, _ = ops.curl_layer_forward(img, mb, L, R, H)
         o_f, _ = ops.curl_layer_forward(img, mf, L, R, H)
         o_u, _ = ops.curl_layer_forward(img, mu, L, R, H)
-        assert torch.equal(o_b, o_f) and torch.equal(o_b, o_u), mk
+        assert torch.equal(o_b, o_u), mk
+        assert float((o_b - o_f).abs().max()) <= 3e-7, mk
         l_b, _ = ops.lab_stage(img, mb, L)
         l_f, _ = ops.lab_stage(img, mf, L)
         assert torch.equal(l_b, l_f), mk
     o_none, _ = ops.curl_layer_forward(img, None, L, R, H)
-    o_ones, _ = ops.curl_layer_forward(img, torch.ones(2, 1, 32, 48, device=dev), L, R, H)
+    o_ones, _ = ops.curl_layer_forward(img, torch.ones(2, 1, 32, 48, dtype=torch.bool, device=dev), L, R, H)
     assert torch.equal(o_none, o_ones)
 
 

@@ -87,7 +87,10 @@ def test_layer_sigma01(twin, golden):
             if mk != "soft":  # 0/1 masks: the binary-mask specialisation (skipped multiplies, masked-out shortcut)
                 outb, _ = twin.layer(1, c[inn], m, L, R, H, binary=True)
                 lsb, _ = twin.layer(0, c[inn], m, L, R, H, binary=True)
-                assert np.array_equal(outb, out) and np.array_equal(lsb, ls), key
+                assert np.array_equal(lsb, ls), key
+                # the layer's binary form also drops the 1e-9 floors of colors.py:205,240 inside the HSV stage
+                # (inputs and outputs there are already in [0,1]): not bit-identical, but far below the bar
+                assert max_err(outb, out) <= 3e-7 and max_err(outb, c[key + "_out"]) <= 1e-5, key
 
 
 def test_layer_error_is_reference_noise_sized(twin):

@@ -1,0 +1,80 @@
+"""A/B timing of two builds of libcurlhip.so in ONE process on ONE GPU (box-to-box clock differences are +-2 %,
+more than most single optimisations): alternating rounds, full and arithmetic-only (CURL_F_DIAG_NO_MEM).
+
+    git stash / checkout the baseline, python -m curl_amd.build --force, cp curl_amd/lib/libcurlhip.so /tmp/base.so ...
+    python tools/ab.py curl_amd/lib/libcurlhip_base.so curl_amd/lib/libcurlhip.so [layer|lab_stage|trispace]
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from curl_amd import _lib  # noqa: E402
+
+
+def bind(path):
+    lib = ctypes.CDLL(os.path.abspath(path))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def main():
+    pa, pb = sys.argv[1], sys.argv[2]
+    what = sys.argv[3] if len(sys.argv) > 3 else "layer"
+    B, H, W = int(os.environ.get("B", 32)), 1000, 1500
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    imgs = [torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
+    out = torch.empty_like(imgs[0])
+    mask = torch.ones(B, 1, H, W, dtype=torch.uint8, device=dev)
+    L, R, Hk = (torch.randn(B, n, device=dev) * 0.1 for n in (48, 48, 64))
+    poly = torch.randn(B, 3, 3, 126, device=dev) * 0.2
+    reg = torch.empty(B, device=dev)
+    libs = {"A": bind(pa), "B": bind(pb)}
+    nb = libs["A"].curl_workspace_bytes(B, 160)
+    ws = torch.empty(nb // 4, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cnt = [0]
+
+    def run(lib, flags):
+        cnt[0] += 1
+        img = imgs[cnt[0] & 1]
+        if what == "layer":
+            rc = lib.curl_layer_fwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
+                                        out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nb, B, H, W, 16, 16, 16, flags, stream)
+        elif what == "lab_stage":
+            rc = lib.curl_lab_stage_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), out.data_ptr(), reg.data_ptr(),
+                                        ws.data_ptr(), nb, B, H, W, 16, flags, stream)
+        else:
+            rc = lib.curl_trispace_fwd_f32(img.data_ptr(), poly.data_ptr(), out.data_ptr(), B, H, W, 126, flags, stream)
+        assert rc == 0, rc
+
+    variants = [(k, d) for d in (0, _lib.F_DIAG_NO_MEM) for k in ("A", "B")]
+    times = {v: [] for v in variants}
+    for _ in range(150):  # clock settle
+        run(libs["A"], 0)
+    torch.cuda.synchronize()
+    for r in range(11):
+        for v in (variants if r % 2 == 0 else variants[::-1]):
+            for _ in range(20):
+                run(libs[v[0]], v[1])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                run(libs[v[0]], v[1])
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 100)
+    for v in variants:
+        t = sorted(times[v])
+        print(f"{what:10s} {v[0]} ({os.path.basename(pa if v[0] == 'A' else pb)}) {'VALU-only' if v[1] else 'full     '} "
+              f"median {t[len(t)//2]*1e3:8.1f} us  min {t[0]*1e3:8.1f} us")
+
+
+if __name__ == "__main__":
+    main()
