@@ -107,6 +107,13 @@ CURL_HD float blend(int mask, float a, float b) {  // mask ? a : b, bit by bit
 #endif
 }
 CURL_HD float keep_if(int mask, float a) { return i2f(mask & f2i(a)); }                             // mask ? a : +0
+CURL_HD float drop_if(int mask, float a) {                                                          // mask ? +0 : a
+#if defined(__HIP_DEVICE_COMPILE__)
+  return i2f(__builtin_amdgcn_bitop3_b32(mask, f2i(a), f2i(a), 0x0C));  // ~mask & a, one instruction
+#else
+  return i2f(~mask & f2i(a));
+#endif
+}
 // x <= thr ? a : b   (thr - x is exact-or-nonzero for x != thr: float32 denormals are on, hipcc default)
 CURL_HD float select_le(float x, float thr, float a, float b) { return blend(neg_mask(thr - x), b, a); }
 
@@ -314,7 +321,7 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 }
 
 // ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
-template <int N>
+template <int N, bool CLAMP12 = false>  // CLAMP12: also clamp channels 1 and 2 to [0,1] (fused stages, see below)
 CURL_HD void lab2rgb_n(PxN<N>& p) {
   float X[3 * N], v[3 * N], g[3 * N], lin[3 * N];
 #pragma unroll
@@ -347,9 +354,30 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #pragma unroll
   for (int i = 0; i < 3 * N; ++i) g[i] = v[i];
   pow_run(g, kInvGamma);
-  fma_run(g, g, 1.055f, -0.055f);
-  scale_run(lin, v, 12.92f);
-  select_le_run(v, v, kLinThr, lin, g);
+  if (!CLAMP12) {
+    fma_run(g, g, 1.055f, -0.055f);
+    scale_run(lin, v, 12.92f);
+    select_le_run(v, v, kLinThr, lin, g);
+  } else {
+    // The next consumer (adjust3, curves.py:36) clamps channels 1 and 2 before using them.  A clamp after the
+    // bitwise select is a separate v_max; on the two branches it rides on the fma / mul that produce them
+    // (clamp(select(a, b)) == select(clamp a, clamp b)), so those two channels go through scalar VOP3 forms.
+    float g0[N], v0[N], l0[N], d[3 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) g0[i] = g[i], v0[i] = v[i];
+    fma_run(g0, g0, 1.055f, -0.055f);
+    scale_run(l0, v0, 12.92f);
+    rsub_run(d, kLinThr, v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = g0[i], lin[i] = l0[i];
+#pragma unroll
+    for (int i = N; i < 3 * N; ++i) {
+      g[i] = clamp01(fmaf(g[i], 1.055f, -0.055f));
+      lin[i] = clamp01(v[i] * 12.92f);
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * N; ++i) v[i] = blend(neg_mask(d[i]), g[i], lin[i]);
+  }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     p.c0[i] = v[i];  // NOT clamped (colors.py:121-123)
@@ -366,17 +394,18 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 // reciprocal needs no Newton step.
 template <int N, bool UNIT = false>
 CURL_HD void rgb2hsv_n(PxN<N>& p) {
-  float r[N], g[N], b[N], mx[N], df[N], rdm[N];
+  float r[N], g[N], b[N], mx[N], nd[N], rdm[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     r[i] = UNIT ? p.c0[i] : clampf(p.c0[i], kHsvFloor, 1.0f);
     g[i] = UNIT ? p.c1[i] : clampf(p.c1[i], kHsvFloor, 1.0f);
     b[i] = UNIT ? p.c2[i] : clampf(p.c2[i], kHsvFloor, 1.0f);
     mx[i] = fmaxf(r[i], fmaxf(g[i], b[i]));
-    df[i] = mx[i] - fminf(r[i], fminf(g[i], b[i]));
+    // nd = -(max - min): +0 when all channels are equal, negative otherwise -- its sign bit IS the "df != 0" mask.
+    nd[i] = fminf(r[i], fminf(g[i], b[i])) - mx[i];
     // 1/df and 1/mx from ONE reciprocal: q = 1/(df*mx), 1/df = q*mx, 1/mx = q*df (df*mx >= 1e-25, no underflow).
     // df == 0 gives inf/NaN; hue and saturation are masked to 0 below.
-    rdm[i] = df[i] * mx[i];
+    rdm[i] = -nd[i] * mx[i];
   }
   CURL_FENCE();
 #pragma unroll
@@ -386,15 +415,19 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
   for (int i = 0; i < N; ++i) {
     float dfi = rdm[i] * mx[i];
     // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum.
-    // [c == mx] as a bit mask: mx - c is +0 exactly when they are equal.
-    float t0 = keep_if(zero_mask(mx[i] - r[i]), (g[i] - b[i]) * dfi);
-    float t1 = keep_if(zero_mask(mx[i] - g[i]), fmaf(b[i] - r[i], dfi, 2.0f));
-    float t2 = keep_if(zero_mask(mx[i] - b[i]), fmaf(r[i] - g[i], dfi, 4.0f));
-    int live = nonzero_mask(df[i]);
+    // [c == mx] as a bit mask: c - mx is negative exactly when c is NOT the maximum (+0 when it is), so one
+    // arithmetic shift gives the complement mask and one and-not applies it.
+    float t0 = drop_if(neg_mask(r[i] - mx[i]), (g[i] - b[i]) * dfi);
+    float t1 = drop_if(neg_mask(g[i] - mx[i]), fmaf(b[i] - r[i], dfi, 2.0f));
+    float t2 = drop_if(neg_mask(b[i] - mx[i]), fmaf(r[i] - g[i], dfi, 4.0f));
+    int live = neg_mask(nd[i]);
     float h = keep_if(live, (t0 + t1) + t2);  // df == 0 -> 0 (colors.py:221)
     // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
-    h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
-    float s = keep_if(live, df[i] * (rdm[i] * df[i]));  // colors.py:234-237: df/mx (0 when df == 0)
+    // (not fract(h/6): two channels tying for the maximum at g == b add up to h6 = 6 exactly, which must stay
+    // hue 1.0, not wrap to 0 -- the hue curves of adjust_hsv are not periodic)
+    if (UNIT) h = fmaf(h, (float)(1.0 / 6.0), keep_if(neg_mask(h), 1.0f));
+    else h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
+    float s = keep_if(live, nd[i] * (rdm[i] * nd[i]));  // colors.py:234-237: df/mx (0 when df == 0)
     p.c0[i] = UNIT ? h : clampf(h, kHsvFloor, 1.0f);  // colors.py:240
     p.c1[i] = UNIT ? s : clampf(s, kHsvFloor, 1.0f);
     p.c2[i] = UNIT ? mx[i] : clampf(mx[i], kHsvFloor, 1.0f);
@@ -462,10 +495,11 @@ CURL_HD float curve_mul(float x_out, float x_in, Affine k) { return x_out * fmaf
 // adjust_rgb / adjust_lab (curves.py:90-133,136-180): curves (0->0),(1->1),(2->2); EVERY apply_curve
 // clamps all three channels (curves.py:36), so channel 0 meets its curve unclamped while channels
 // 1 and 2 are clamped first.
+template <bool CLAMPED12 = false>  // CLAMPED12: channels 1 and 2 arrive clamped (lab2rgb_n<N, true>)
 CURL_HD Px adjust3(Px p, Affine k0, Affine k1, Affine k2) {
   Px o;
   o.c0 = clamp01(curve_mul(p.c0, p.c0, k0));
-  float c1 = clamp01(p.c1), c2 = clamp01(p.c2);
+  float c1 = CLAMPED12 ? p.c1 : clamp01(p.c1), c2 = CLAMPED12 ? p.c2 : clamp01(p.c2);
   o.c1 = clamp01(curve_mul(c1, c1, k1));
   o.c2 = clamp01(curve_mul(c2, c2, k2));
   return o;
@@ -557,7 +591,7 @@ struct LayerCoef {
 // model.py:151-157 : rgb2lab -> adjust_lab -> *mask -> lab2rgb
 // BINARY = the mask is known to be exactly 0 or 1 (bool / uint8 masks, or no mask at all): x*1 == x, so the
 // multiply is dropped for m == 1, and pixels with m == 0 are finished by the caller (lab_stage_masked_out).
-template <bool BINARY, int N>
+template <bool BINARY, int N, bool CLAMP12 = false>
 CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
   rgb2lab_n<N>(p);
 #pragma unroll
@@ -570,7 +604,7 @@ CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
     }
     p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
   }
-  lab2rgb_n<N>(p);
+  lab2rgb_n<N, CLAMP12>(p);
 }
 // what model.py:154-157 yields where the mask is 0: lab2rgb(0,0,0), the same colour for every such pixel
 CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }
@@ -582,10 +616,10 @@ CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }
 template <bool BINARY, int N>
 CURL_HD void curl_layer_n(PxN<N>& p, const float (&m)[N], const LayerCoef& k) {
   PxN<N> in = p;
-  lab_stage_n<BINARY, N>(p, m, k.lab);
+  lab_stage_n<BINARY, N, true>(p, m, k.lab);  // channels 1, 2 come back clamped: adjust3 would clamp them first
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k.rgb[0], k.rgb[1], k.rgb[2]);  // model.py:159
+    Px o = adjust3<true>(Px{p.c0[i], p.c1[i], p.c2[i]}, k.rgb[0], k.rgb[1], k.rgb[2]);  // model.py:159
     if (!BINARY) {                                                                  // model.py:160
       o.c0 *= m[i];
       o.c1 *= m[i];

@@ -146,3 +146,23 @@ def test_file_edge_scalars(twin):
     inside = (x >= 0) & (x <= 1)
     assert np.array_equal(q[inside], (x[inside] * np.float32(255)).astype(np.uint8))
     assert q[-3] == 0 and q[-2] == 255
+
+
+@pytest.mark.parametrize("seed", [3034, 1, 2])
+def test_layer_binary_form_on_ties_and_out_of_range_inputs(twin, seed):
+    """Inputs in [-0.1, 1.1] drive channels into the clamps, so the HSV stage sees exact ties (g == b == 1 adds up
+    to hue sextant 6 = hue 1.0, which must NOT wrap to 0: the hue curves are not periodic) and exact zeros (where
+    the binary form has dropped the reference's 1e-9 floors).  Caught a fract()-based hue wrap once."""
+    B, H, W = 2, 1, 1024
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, H, W, generator=g) * 1.2 - 0.1
+    img[0, :, 0, :64] = torch.round(img[0, :, 0, :64] * 4) / 4          # coarse grid: many exact ties
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.25
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (48, 48, 64))
+    ref, _ = O.curl_layer(img, mask.float(), L, R, Hk)
+    r64, _ = O.curl_layer(img.double(), mask.double(), L.double(), R.double(), Hk.double())
+    noise = max_err(ref.numpy(), r64.numpy())  # the reference's own float32 rounding on these inputs (~1e-5)
+    for binary in (True, False):
+        out, _ = twin.layer(1, img.numpy(), mask.float().numpy(), L.numpy(), R.numpy(), Hk.numpy(), binary=binary)
+        assert max_err(out, r64.numpy()) <= 1.5 * noise + 1e-6, binary
+        assert max_err(out, ref.numpy()) <= 3e-5, binary
