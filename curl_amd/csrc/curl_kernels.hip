@@ -198,6 +198,9 @@ struct Tile {
   typename Pack<VEC>::T mf[MK == CURL_MASK_F32 ? U : 1];
   typename Pack<VEC>::M mb[MK == CURL_MASK_U8 ? U : 1];
   typename Pack<VEC>::M wm[U];  // FMT_U8HWC: white-background mask bytes
+#ifdef CURL_DIAG_NO_DEP
+  typename Pack<VEC>::T raw[U];
+#endif
 };
 
 // a*b rounded, then + c rounded -- what two eager ops produce (HIP's __fmul_rn/__fadd_rn are plain operators and
@@ -265,6 +268,15 @@ __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs&
     t.x0[u] = ld<NT>(p0 + i);
     t.x1[u] = ld<NT>(p0 + plane + i);
     t.x2[u] = ld<NT>(p0 + 2 * plane + i);
+#ifdef CURL_DIAG_NO_DEP
+    // experiment build only (tools/ab.py): the loads are issued and must land before the stores, but the
+    // arithmetic runs on synthetic values -- separates "waiting for data" from "sharing the chip with traffic"
+    t.raw[u] = t.x0[u] + t.x1[u] + t.x2[u];
+    {
+      float f = (float)(i & 1023u) * (1.0f / 1024.0f);
+      t.x0[u] = T(f), t.x1[u] = T(1.0f - f), t.x2[u] = T(0.5f * f + 0.1f);
+    }
+#endif
     if (MK == CURL_MASK_U8) t.mb[u] = ld<NT>(reinterpret_cast<const M*>(a.mask) + mask_off + i);
     if (MK == CURL_MASK_F32) t.mf[u] = ld<NT>(reinterpret_cast<const T*>(a.mask) + mask_off + i);
   }
@@ -280,7 +292,7 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
   for (int u = 0; u < U; ++u) {
     unsigned i = base + u * 256u;
     T y0, y1, y2;
-    bool live = true;
+    bool live = true, full = false;
     if (Op::kMask && MK != CURL_MASK_NONE) {
       // Masks are foreground masks: whole waves are often masked out.  Where every lane of the wave has
       // m == 0 for all its pixels the result is a constant (0 for the layer, lab2rgb(0,0,0) for the Lab
@@ -290,8 +302,38 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
       for (int e = 0; e < VEC; ++e)
         lane_live |= (MK == CURL_MASK_U8) ? (mlane(t.mb[u], e) != 0.0f) : (lane(t.mf[u], e) != 0.0f);
       live = __builtin_amdgcn_ballot_w64(lane_live) != 0ull;
+      if constexpr (MK == CURL_MASK_U8) {
+        // ... and just as often fully inside the foreground: every mask byte of the wave non-zero.  Then the
+        // mask is the constant 1 and its conversions, multiplies and blends go (wave-uniform branch again).
+        unsigned w;
+        if constexpr (VEC == 4) {
+          w = __builtin_bit_cast(unsigned, t.mb[u]);
+          w = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // bit 7 of each byte: byte != 0
+          w ^= 0x80808080u;                                           // 0 iff all four are non-zero
+        } else {
+          w = t.mb[u] ? 0u : 1u;
+        }
+        full = __builtin_amdgcn_ballot_w64(w == 0u) == ~0ull;
+      }
     }
-    if (live) {
+    if (live && full) {
+      PxN<VEC> px;
+      float one[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        px.c0[e] = lane(t.x0[u], e);
+        px.c1[e] = lane(t.x1[u], e);
+        px.c2[e] = lane(t.x2[u], e);
+        one[e] = 1.0f;
+      }
+      Op::template apply_n<true, VEC>(px, one, k, i * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        set_lane(y0, e, px.c0[e]);
+        set_lane(y1, e, px.c1[e]);
+        set_lane(y2, e, px.c2[e]);
+      }
+    } else if (live) {
       PxN<VEC> px;
       float mm[VEC];
 #pragma unroll
@@ -329,6 +371,9 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
       }
     }
     bool keep = true;
+#ifdef CURL_DIAG_NO_DEP
+    keep = lane(t.raw[u], 0) != -123.0f;  // always true; ties the stores to the loads
+#endif
     if (a.no_mem) {  // every output feeds the (never true) condition, so nothing can be sunk or dropped
       float chk = 0.0f;
 #pragma unroll

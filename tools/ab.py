@@ -54,6 +54,7 @@ def main():
             rc = lib.curl_trispace_fwd_f32(img.data_ptr(), poly.data_ptr(), out.data_ptr(), B, H, W, 126, flags, stream)
         assert rc == 0, rc
 
+    extra = {"A": int(os.environ.get("FLAGS_A", "0"), 0), "B": int(os.environ.get("FLAGS_B", "0"), 0)}  # e.g. 0x200 = U=2
     variants = [(k, d) for d in (0, _lib.F_DIAG_NO_MEM) for k in ("A", "B")]
     times = {v: [] for v in variants}
     for _ in range(150):  # clock settle
@@ -62,11 +63,11 @@ def main():
     for r in range(11):
         for v in (variants if r % 2 == 0 else variants[::-1]):
             for _ in range(20):
-                run(libs[v[0]], v[1])
+                run(libs[v[0]], v[1] | extra[v[0]])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(100):
-                run(libs[v[0]], v[1])
+                run(libs[v[0]], v[1] | extra[v[0]])
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 100)
