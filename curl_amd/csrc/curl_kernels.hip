@@ -142,6 +142,7 @@ struct StreamArgs {
   unsigned W, H;  // image size in pixels (ops that need pixel coordinates)
   int op_flag;    // op-specific (trispace: residual only)
   const uint8_t* white;  // FMT_U8HWC only: [B,H,W] 'L' mask of infer.py:39,46 (out*m + (1-m), m = L/255) or NULL
+  unsigned units, segs;  // Op::kRowTiles only: VEC-pixel groups per image row, blocks per row
 };
 // pixel formats at the kernel's edges: planar float32 NCHW (what the reference's tensors are), or the file edge's
 // interleaved bytes (PIL HWC uint8 in, to_pil_image / astype('uint8') out) converted in registers
@@ -285,7 +286,7 @@ __device__ __forceinline__ void load_tile(Tile<VEC, U, MK>& t, const StreamArgs&
 template <class Op, int VEC, int U, int MK, bool NT, int FMT>
 __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const StreamArgs& a,
                                               typename Pack<VEC>::T* q0, size_t plane, unsigned base,
-                                              const typename Op::K& k) {
+                                              const typename Op::K& k, bool valid) {
   typedef typename Pack<VEC>::T T;
   constexpr bool kBinary = (MK != CURL_MASK_F32);  // none / bool / uint8: the mask is exactly 0 or 1
 #pragma unroll
@@ -394,7 +395,7 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) q[ch][e] = unit_to_u8(c[ch]);
       }
-      if (i < a.n) {
+      if (i < a.n && valid) {
         if constexpr (VEC == 4) {
           unsigned* w = reinterpret_cast<unsigned*>(q0) + 3 * (size_t)i;
           st<NT>(w, q[0][0] | (q[1][0] << 8) | (q[2][0] << 16) | (q[0][1] << 24));
@@ -405,7 +406,7 @@ __device__ __forceinline__ void compute_store(const Tile<VEC, U, MK>& t, const S
           w[0] = (uint8_t)q[0][0], w[1] = (uint8_t)q[1][0], w[2] = (uint8_t)q[2][0];
         }
       }
-    } else if (i < a.n && keep) {
+    } else if (i < a.n && keep && valid) {
       st<NT>(q0 + i, y0);
       st<NT>(q0 + plane + i, y1);
       st<NT>(q0 + 2 * plane + i, y2);
@@ -422,10 +423,22 @@ __global__ __launch_bounds__(256, Op::kMinWavesPerSimd) void stream_kernel(Strea
   __builtin_assume(a.n <= (1u << 28));  // H*W <= 2^30 (checked on the host): byte offsets fit 32 bits
   const float* table = a.coef ? a.coef + (size_t)img * a.coef_stride : nullptr;
   __shared__ float s_table[Op::kLdsFloats > 0 ? Op::kLdsFloats : 1];
+  unsigned row = 0, base = chunk * (256u * U) + threadIdx.x;
+  bool valid = true;
+  if constexpr (Op::kRowTiles) {
+    row = chunk / a.segs;  // wave-uniform, once per block
+    const unsigned in_row = (chunk - row * a.segs) * blockDim.x + threadIdx.x;
+    valid = in_row < a.units;                          // lanes past the row end: loads clamp, stores are dropped
+    base = row * a.units + min(in_row, a.units - 1u);
+  }
   if constexpr (Op::kLdsFloats > 0) {
     // a per-image table too large for SGPRs (1134 polynomial coefficients): one coalesced copy into LDS, then
     // every lane reads the same address (broadcast ds_read_b128, conflict-free)
-    for (int i = threadIdx.x; i < Op::kLdsFloats; i += 256) s_table[i] = table[Op::stage_index(i)];
+    if constexpr (Op::kRowTiles) {
+      for (unsigned i = threadIdx.x; i < (unsigned)Op::kLdsFloats; i += blockDim.x) s_table[i] = Op::stage_value(table, i, row, a);
+    } else {
+      for (int i = threadIdx.x; i < Op::kLdsFloats; i += 256) s_table[i] = table[Op::stage_index(i)];
+    }
     __syncthreads();
     table = s_table;
   }
@@ -436,10 +449,9 @@ __global__ __launch_bounds__(256, Op::kMinWavesPerSimd) void stream_kernel(Strea
   const T* p0 = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.in) + (size_t)img * image_bytes);
   T* q0 = reinterpret_cast<T*>(reinterpret_cast<char*>(a.out) + (size_t)img * image_bytes);
   const size_t mask_off = (size_t)img * plane;
-  const unsigned base = chunk * (256u * U) + threadIdx.x;
   Tile<VEC, U, MK> t;
   load_tile<VEC, U, MK, NT, FMT>(t, a, p0, plane, mask_off, base);
-  compute_store<Op, VEC, U, MK, NT, FMT>(t, a, q0, plane, base, k);
+  compute_store<Op, VEC, U, MK, NT, FMT>(t, a, q0, plane, base, k, valid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,6 +462,9 @@ struct OpDefaults {
   static constexpr bool kSingleTileShape = false;
   static constexpr int kLdsFloats = 0;  // per-image table the block stages in LDS before the tile (0 = none)
   static constexpr int kMinWavesPerSimd = 1;  // __launch_bounds__ second argument (register budget)
+  // true: a block never crosses an image row (grid.x = blocks per row x rows, blockDim.x <= 256 follows the row
+  // width) and the LDS table is built per row by Op::stage_value(table, i, row, args)
+  static constexpr bool kRowTiles = false;
 };
 #define CONVERTER_OP(NAME, FN)                                                           \
   struct NAME : OpDefaults {                                                             \
@@ -601,6 +616,43 @@ struct OpTriSpace : OpDefaults {
       }
     }
     trispace_n<V, N, true>(p, xw, yh, k.coef, k.residual_only);
+  }
+  static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
+};
+
+// The spatial polynomial path, one image row per block.  cat_coords' y = row/height is the same for every pixel
+// of a row, so the block folds y into the coefficients first (9 polynomials x 70 collapsed coefficients, <= 4
+// FMAs each, a handful per thread; collapse_coef) and leaves them in LDS in the consumption order of the
+// 4-variable Horner scheme: a pixel then costs 9 x 69 FMAs instead of 9 x 125.
+struct OpTriSpaceRows : OpDefaults {
+  struct K {
+    const float* coef;
+    unsigned W;
+    float fW;
+    bool residual_only;
+  };
+  static constexpr bool kMask = false;
+  static constexpr int kUnroll = 1;
+  static constexpr bool kSingleTileShape = true;
+  static constexpr bool kRowTiles = true;
+  static constexpr int kLdsFloats = 9 * PolyEval<4>::kCoeffs;
+  static constexpr int kMinWavesPerSimd = CURL_TRISPACE_WAVES;
+  static __device__ __forceinline__ float stage_value(const float* coef_img, unsigned i, unsigned row, const StreamArgs& a) {
+    constexpr unsigned NC4 = PolyEval<4>::kCoeffs, NC5 = PolyEval<5>::kCoeffs;
+    unsigned q = i / NC4, pos = i - q * NC4;
+    return collapse_coef(coef_img + q * NC5, (int)pos, (float)row / (float)a.H);  // row / height: true division
+  }
+  static constexpr bool kBlendMaskedOut = false;
+  static __device__ __forceinline__ K load(const float* coef_row, const StreamArgs& a) {
+    return K{coef_row, a.W, (float)a.W, a.op_flag != 0};
+  }
+  template <bool, int N>
+  static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k, unsigned pix0) {
+    float xw[N], yh[N];
+    unsigned col = pix0 % k.W;  // a row tile never wraps
+#pragma unroll
+    for (int i = 0; i < N; ++i) xw[i] = (float)(col + i) / k.fW, yh[i] = 0.0f;  // column / width: true division
+    trispace_n<4, N, true>(p, xw, yh, k.coef, k.residual_only);
   }
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
 };
@@ -1233,7 +1285,29 @@ struct Geometry {
   unsigned n;    // plane length in vec units
   unsigned blocks_per_image, n_blocks, n_images;
   int nt;  // non-temporal loads and stores (float4 kernels)
+  unsigned threads = 256;      // block size (row-tiled ops: follows the row width)
+  unsigned units = 0, segs = 0;  // row-tiled ops: vec groups per row, blocks per row
 };
+// Row-tiled ops (Op::kRowTiles): a block covers (part of) ONE image row.  Block size = the multiple of 64 lanes
+// (<= 256) that wastes the fewest lanes on the last block of a row, larger preferred: 1500 px = 375 float4 groups
+// -> 2 blocks of 192 lanes (2.3 % idle) rather than 256 + 119.
+static int make_row_geometry(Geometry& g, int B, int H, int W) {
+  if (g.vec == 4 && W % 4 != 0) g.vec = 1;  // rows must start on a float4 boundary
+  g.units = (unsigned)(W / g.vec);
+  unsigned best_t = 64, best_waste = ~0u;
+  for (unsigned t = 64; t <= 256; t += 64) {
+    unsigned segs = (g.units + t - 1) / t, waste = segs * t - g.units;
+    if (waste <= best_waste) best_waste = waste, best_t = t;
+  }
+  g.threads = best_t;
+  g.segs = (g.units + best_t - 1) / best_t;
+  g.n = (unsigned)((size_t)H * W / g.vec);
+  uint64_t per_image = (uint64_t)g.segs * (uint64_t)H;
+  if (per_image * (uint64_t)B > 0x7fffffffull || per_image > 0x7fffffffull) return fail(CURL_E_SHAPE, "grid too large");
+  g.blocks_per_image = (unsigned)per_image;
+  g.n_blocks = (unsigned)(per_image * (uint64_t)B);
+  return 0;
+}
 
 // Library defaults chosen from the sweep in DESIGN.md (profiles/).
 
@@ -1261,7 +1335,7 @@ static int make_geometry(Geometry& g, const void* p0, const void* p1, const void
 
 template <class Op, int VEC, int MK, bool NT>
 static hipError_t launch_u(const Geometry& g, const StreamArgs& a, hipStream_t s) {
-  dim3 grid(g.blocks_per_image, g.n_images), block(256);
+  dim3 grid(g.blocks_per_image, g.n_images), block(g.threads);
   if constexpr (Op::kSingleTileShape) {
     // very large ops (polynomial layers) are built for one tile shape only
     hipLaunchKernelGGL((stream_kernel<Op, VEC, 1, MK, NT>), grid, block, 0, s, a);
@@ -1294,6 +1368,8 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   Geometry g;
   if (Op::kSingleTileShape) flags &= ~CURL_F_TUNE_UNROLL_MASK;
   if (int rc = make_geometry(g, in, out, mask, mask_kind, B, H, W, flags, Op::kUnroll)) return rc;
+  if constexpr (Op::kRowTiles)
+    if (int rc = make_row_geometry(g, B, H, W)) return rc;
   StreamArgs a;
   a.in = in;
   a.out = out;
@@ -1308,6 +1384,7 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
   a.H = (unsigned)H;
   a.op_flag = op_flag;
   a.white = nullptr;
+  a.units = g.units, a.segs = g.segs;
   hipError_t e;
   if constexpr (Op::kMask) {
     e = (mask_kind == CURL_MASK_U8)    ? launch_v<Op, CURL_MASK_U8>(g, a, s)
@@ -1323,7 +1400,7 @@ static int launch_stream(const float* in, float* out, const void* mask, int mask
 // FMT_U8HWC launch: interleaved bytes in and out, optional white-background mask; one tile shape per op
 template <class Op, int MK>
 static hipError_t launch_u8_v(const Geometry& g, const StreamArgs& a, hipStream_t s) {
-  dim3 grid(g.blocks_per_image, g.n_images), block(256);
+  dim3 grid(g.blocks_per_image, g.n_images), block(g.threads);
   constexpr int U = Op::kSingleTileShape ? 1 : Op::kUnroll;
   if (g.vec == 4)
     hipLaunchKernelGGL((stream_kernel<Op, 4, U, MK, true, FMT_U8HWC>), grid, block, 0, s, a);
@@ -1346,6 +1423,8 @@ static int launch_stream_u8(const uint8_t* in, uint8_t* out, const void* mask, i
   g.n = (unsigned)(HW / g.vec);
   unsigned per_chunk = 256u * (unsigned)g.unroll;
   g.blocks_per_image = (g.n + per_chunk - 1) / per_chunk;
+  if constexpr (Op::kRowTiles)
+    if (int rc = make_row_geometry(g, B, H, W)) return rc;
   StreamArgs a{};
   a.in = reinterpret_cast<const float*>(in);
   a.out = reinterpret_cast<float*>(out);
@@ -1360,6 +1439,7 @@ static int launch_stream_u8(const uint8_t* in, uint8_t* out, const void* mask, i
   a.W = (unsigned)W;
   a.H = (unsigned)H;
   a.op_flag = op_flag;
+  a.units = g.units, a.segs = g.segs;
   hipError_t e;
   if constexpr (Op::kMask) {
     e = (mask_kind == CURL_MASK_U8)    ? launch_u8_v<Op, CURL_MASK_U8>(g, a, s)
@@ -1412,7 +1492,7 @@ static int run_prep(const float* r0, int n0, int K0, const float* r1, int n1, in
 
 template <int VEC>
 static hipError_t launch_chain_u(const Geometry& g, const ChainArgs& a, hipStream_t s) {
-  dim3 grid(g.blocks_per_image, g.n_images), block(256);
+  dim3 grid(g.blocks_per_image, g.n_images), block(g.threads);
   switch (g.unroll) {
     case 1:
       hipLaunchKernelGGL((chain_kernel<VEC, 1>), grid, block, 0, s, a);
@@ -1456,7 +1536,6 @@ static int launch_chain(const float* in, float* out, const float* knots, unsigne
 static int chain_mode(unsigned flags) { return (flags & CURL_F_EXACT_ORDER) ? 1 : (flags & CURL_F_PWL) ? 2 : 0; }
 
 // pixels per thread of the accumulation pass: enough to amortise the 3*T-value block reduction (>= 16), few enough
-// that the grid still covers the chip several times over (~2048 blocks)
 static unsigned tri_ppt(int B, size_t HW) {
   size_t p = HW * 9 * (size_t)B / (256u * 2048u);
   return (unsigned)(p < 16 ? 16 : (p > 64 ? 64 : p));
@@ -1721,7 +1800,7 @@ int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int
   int ro = (flags & CURL_F_RESIDUAL_ONLY) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (num_coeffs == 126)
-    return launch_stream<OpTriSpace<5>>(img, out, nullptr, 0, coeffs, 9 * 126, B, H, W, flags, s, "trispace", ro);
+    return launch_stream<OpTriSpaceRows>(img, out, nullptr, 0, coeffs, 9 * 126, B, H, W, flags, s, "trispace_rows", ro);
   return launch_stream<OpTriSpace<3>>(img, out, nullptr, 0, coeffs, 9 * 35, B, H, W, flags, s, "trispace", ro);
 }
 
@@ -1735,7 +1814,8 @@ int curl_trispace_fwd_u8hwc(const uint8_t* img, const float* coeffs, const uint8
   if (flags) return fail(CURL_E_FLAGS, "unsupported flag bit for this entry point (the byte output is an image)");
   hipStream_t s = (hipStream_t)stream;
   if (num_coeffs == 126)
-    return launch_stream_u8<OpTriSpace<5>>(img, out, nullptr, 0, white_mask, coeffs, 9 * 126, B, H, W, s, "trispace_u8hwc");
+    return launch_stream_u8<OpTriSpaceRows>(img, out, nullptr, 0, white_mask, coeffs, 9 * 126, B, H, W, s,
+                                            "trispace_rows_u8hwc");
   return launch_stream_u8<OpTriSpace<3>>(img, out, nullptr, 0, white_mask, coeffs, 9 * 35, B, H, W, s, "trispace_u8hwc");
 }
 

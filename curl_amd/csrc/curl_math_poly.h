@@ -50,6 +50,13 @@ struct PolyEval<5> {
   static CURL_HD void monomials(float (&m)[42], const float (&pw)[5][5]) { mono_d4_v5<C>(m, pw); }
 };
 template <>
+struct PolyEval<4> {  // 3 colour channels + x/W: the per-row collapsed form of the 5-variable polynomial (below)
+  static constexpr int kCoeffs = 70;
+  template <class F, bool SEQ, int NP>
+  static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][4], const float* c) { poly_d4_v4<F, SEQ, NP>(out, v, c); }
+  static CURL_HD int order(int pos) { return kPolyOrder_d4_v4[pos]; }
+};
+template <>
 struct PolyEval<3> {
   static constexpr int kCoeffs = 35;
   template <class F, bool SEQ, int NP>
@@ -126,7 +133,7 @@ CURL_HD void sigmoid_run(float (&x)[M]) {
   for (int i = 0; i < M; ++i) x[i] = 1.0f + x[i];
   CURL_FENCE();
 #pragma unroll
-  for (int i = 0; i < M; ++i) x[i] = rcp_refined(x[i]);
+  for (int i = 0; i < M; ++i) x[i] = hw_rcp(x[i]);  // 1 ulp: 6e-8 of a value in (0,1)
   CURL_FENCE();
 }
 
@@ -147,10 +154,8 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
       vars[0][i] = q.c0[i];
       vars[1][i] = q.c1[i];
       vars[2][i] = q.c2[i];
-      if (V == 5) {
-        vars[V - 2][i] = xw[i];
-        vars[V - 1][i] = yh[i];
-      }
+      if (V >= 4) vars[3][i] = xw[i];
+      if (V == 5) vars[4][i] = yh[i];
     }
   };
   auto squash = [&]() {  // sigmoid over the 3N outputs
@@ -195,7 +200,7 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
   squash();
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    Px q = hsv2rgb(Px{o[0][i], o[1][i], o[2][i]});
+    Px q = hsv2rgb<true>(Px{o[0][i], o[1][i], o[2][i]});  // sigmoid outputs: already in [0,1]
     res[0][i] += 2.0f * (q.c0 - 0.5f);
     res[1][i] += 2.0f * (q.c1 - 0.5f);
     res[2][i] += 2.0f * (q.c2 - 0.5f);
@@ -210,6 +215,25 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
       p.c2[i] = clamp01(p.c2[i] + res[2][i]);
     }
   }
+}
+
+// ---------------------------------------------------------------- one pixel row at a time: y is a constant
+// cat_coords' last variable is row/height: the same value for every pixel of a row.  Writing
+//   P(c0, c1, c2, x, y) = sum_m m(c0, c1, c2, x) * (sum_j y^j coef[(m, j)])
+// the inner sums are 70 numbers per polynomial and row (Horner in y, <= 4 FMAs each), after which a pixel costs
+// 69 FMAs per output instead of 125.  collapse_coef returns the collapsed coefficient the 4-variable Horner
+// scheme consumes at position `pos`; c126 = the reference-order coefficients of one polynomial.
+CURL_HD float collapse_coef(const float* c126, int pos, float y) {
+  const unsigned short* src = kPolyCollapse_d4_v5[kPolyOrder_d4_v4[pos]];
+  float acc = 0.0f;
+  bool started = false;
+#pragma unroll
+  for (int j = 4; j >= 0; --j) {
+    if (src[j] == 0xFFFF) continue;
+    acc = started ? fmaf(acc, y, c126[src[j]]) : c126[src[j]];
+    started = true;
+  }
+  return acc;
 }
 
 // ---------------------------------------------------------------- backward of the polynomial path

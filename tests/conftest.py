@@ -127,6 +127,14 @@ def twin():
             return out
 
         @staticmethod
+        def trispace_rows(img, coeffs, residual_only=False):
+            img, coeffs = f32(img), f32(coeffs)
+            B, _, Hh, W = img.shape
+            out = np.empty_like(img)
+            lib.twin_trispace_rows(P(img), P(coeffs), P(out), B, Hh, W, int(residual_only))
+            return out
+
+        @staticmethod
         def poly_layer(img, coeffs):
             img, coeffs = f32(img), f32(coeffs)
             B, V, Hh, W = img.shape

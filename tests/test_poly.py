@@ -61,6 +61,17 @@ def test_twin_trispace(twin, golden, s, tol):
     assert max_err(twin.trispace(g["img"], g[s + "_coeffs35"], residual_only=True), g[f"{s}_img_residual_nonspatial"]) <= tol
 
 
+@pytest.mark.parametrize("s,tol", [("s02", 1e-5), ("s1", 2e-5)])
+def test_twin_trispace_row_collapsed(twin, golden, s, tol):
+    """The spatial kernel evaluates a 4-variable polynomial per row (y folded into 70 coefficients per row):
+    same values as the reference's 5-variable form."""
+    g = golden("poly")
+    for nm in ("img", "img8"):
+        assert max_err(twin.trispace_rows(g[nm], g[s + "_coeffs"], residual_only=True), g[f"{s}_{nm}_residual"]) <= tol, nm
+        assert max_err(twin.trispace_rows(g[nm], g[s + "_coeffs"]), g[f"{s}_{nm}_image"]) <= tol, nm
+        assert max_err(twin.trispace_rows(g[nm], g[s + "_coeffs"]), twin.trispace(g[nm], g[s + "_coeffs"])) <= 3e-6, nm
+
+
 @pytest.mark.parametrize("nc,residual_only", [(126, False), (126, True), (35, False)])
 def test_twin_trispace_backward_vs_oracle_autograd(twin, nc, residual_only):
     """d loss / d coeffs of the fused polynomial path vs autograd through the oracle (= the reference's ops)."""

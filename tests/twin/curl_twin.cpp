@@ -188,6 +188,28 @@ int twin_trispace(const float* img, const float* coeffs, float* out, int B, int 
   return 0;
 }
 // ChannelPolyLayer / Deg4MobilePolyLayer forward: img [B,V,H,W], coeffs [B,3,NC] -> out [B,3,H,W]
+// the per-row collapsed evaluation of the spatial polynomial path (what trispace_rows_kernel does)
+int twin_trispace_rows(const float* img, const float* coeffs, float* out, int B, int H, int W, int residual_only) {
+  const size_t HW = (size_t)H * W;
+  for (int b = 0; b < B; ++b) {
+    const float* c = coeffs + (size_t)b * 9 * 126;
+    for (int r = 0; r < H; ++r) {
+      float row_coef[9 * 70];
+      const float y = (float)r / (float)H;
+      for (int q = 0; q < 9; ++q)
+        for (int pos = 0; pos < 70; ++pos) row_coef[q * 70 + pos] = collapse_coef(c + q * 126, pos, y);
+      for (int col = 0; col < W; ++col) {
+        size_t i = (size_t)r * W + col;
+        PxN<1> p{{img[(b * 3 + 0) * HW + i]}, {img[(b * 3 + 1) * HW + i]}, {img[(b * 3 + 2) * HW + i]}};
+        float xw[1] = {(float)col / (float)W}, yh[1] = {0.0f};
+        trispace_n<4, 1, true>(p, xw, yh, row_coef, residual_only != 0);
+        out[(b * 3 + 0) * HW + i] = p.c0[0], out[(b * 3 + 1) * HW + i] = p.c1[0], out[(b * 3 + 2) * HW + i] = p.c2[0];
+      }
+    }
+  }
+  return 0;
+}
+
 int twin_poly_layer(const float* img, const float* coeffs, float* out, int B, long HW, int V) {
   const int NC = V == 5 ? 126 : 35;
   for (int b = 0; b < B; ++b)

@@ -133,6 +133,22 @@ def gen_monomials(degree, nvars, chunk):
     return "\n".join(out)
 
 
+def gen_collapse(degree, nvars):
+    """Collapsing the LAST variable: P(v0..v_{n-2}, y) = sum_m m(v0..v_{n-2}) * (sum_j y^j c[(m, j)]).
+    For a pixel row the last variable (row / height) is one value, so the inner sums are computed once per row
+    and the per-pixel polynomial has nvars-1 variables: 70 coefficients instead of 126 for degree 4.
+    Table: for every monomial of the (nvars-1)-variable reference order, the reference indices of
+    (m, j = 0..degree), 0xFFFF where |m| + j > degree."""
+    full = {t: i for i, t in enumerate(powers(degree, nvars))}
+    small = powers(degree, nvars - 1)
+    rows = []
+    for m in small:
+        rows.append("{" + ", ".join(str(full[m + (j,)]) if sum(m) + j <= degree else "0xFFFF" for j in range(degree + 1)) + "}")
+    return (f"// y-collapse of the degree-{degree}, {nvars}-variable polynomial onto {nvars - 1} variables: row m = reference index of\n"
+            f"// the {nvars - 1}-variable monomial; entry j = reference index ({nvars} variables) of m * v{nvars - 1}^j, 0xFFFF = none\n"
+            f"constexpr unsigned short kPolyCollapse_d{degree}_v{nvars}[{len(small)}][{degree + 1}] = {{\n  " + ",\n  ".join(rows) + "};\n").replace("\\n", "\n")
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "curl_amd", "csrc", "poly_horner.inc")
@@ -140,9 +156,10 @@ def main():
              "// Multivariate Horner evaluators in the coefficient order of the reference's generate_powers\n"
              "// (model.py:222-246).  F = float (host twin) or a packed 2-pixel vector (gfx950: v_pk_fma_f32).\n"
              "// CURL_POLY_SPLAT(c): F from a scalar; CURL_POLY_FMA(a, v, c): a*v + splat(c); CURL_POLY_FMAV(a, v, q): a*v + q.\n"]
-    for degree, nvars in ((4, 5), (4, 3)):
+    for degree, nvars in ((4, 5), (4, 3), (4, 4)):
         table, code = gen(degree, nvars)
         parts.append(code)
+    parts.append(gen_collapse(4, 5))
     parts.append(gen_monomials(4, 5, 42))
     parts.append(gen_monomials(4, 3, 35))
     open(out, "w").write("\n".join(parts))
