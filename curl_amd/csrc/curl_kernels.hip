@@ -628,7 +628,7 @@ struct OpTriSpaceRows : OpDefaults {
   struct K {
     const float* coef;
     unsigned W;
-    float fW;
+    float fW, rW;
     bool residual_only;
   };
   static constexpr bool kMask = false;
@@ -644,14 +644,14 @@ struct OpTriSpaceRows : OpDefaults {
   }
   static constexpr bool kBlendMaskedOut = false;
   static __device__ __forceinline__ K load(const float* coef_row, const StreamArgs& a) {
-    return K{coef_row, a.W, (float)a.W, a.op_flag != 0};
+    return K{coef_row, a.W, (float)a.W, 1.0f / (float)a.W, a.op_flag != 0};
   }
   template <bool, int N>
   static __device__ __forceinline__ void apply_n(PxN<N>& p, const float (&)[N], const K& k, unsigned pix0) {
     float xw[N], yh[N];
     unsigned col = pix0 % k.W;  // a row tile never wraps
 #pragma unroll
-    for (int i = 0; i < N; ++i) xw[i] = (float)(col + i) / k.fW, yh[i] = 0.0f;  // column / width: true division
+    for (int i = 0; i < N; ++i) xw[i] = div_small((float)(col + i), k.fW, k.rW), yh[i] = 0.0f;  // column / width
     trispace_n<4, N, true>(p, xw, yh, k.coef, k.residual_only);
   }
   static __device__ __forceinline__ Px masked_out(const K&) { return Px{0.0f, 0.0f, 0.0f}; }
@@ -1074,6 +1074,7 @@ __device__ __forceinline__ void coef_grad_block(const CoefGradArgs& a, unsigned 
     for (int j = 0; j < T; ++j) acc[o][j] = 0.0f;
   unsigned i = tile * 256u * a.ppt + threadIdx.x;
   unsigned row = i / a.W, col = i - row * a.W;
+  const float rW = 1.0f / a.fW, rH = 1.0f / a.fH;
   auto fetch = [&](float (&d)[6], unsigned at) {  // clamped: always a valid pixel, masked below
     const float* p = base + min(at, HW - 1);
 #pragma unroll
@@ -1088,8 +1089,8 @@ __device__ __forceinline__ void coef_grad_block(const CoefGradArgs& a, unsigned 
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = cur[c], g[c] = live ? cur[3 + c] : 0.0f;
     if (V == 5) {
-      v[V - 2] = (float)col / a.fW;
-      v[V - 1] = (float)row / a.fH;
+      v[V - 2] = div_small((float)col, a.fW, rW);
+      v[V - 1] = div_small((float)row, a.fH, rH);
     }
     coef_grad_accumulate<V, C>(acc, v, g);
     CURL_FENCE();  // keep the wait for the prefetch at the end of the step

@@ -170,6 +170,11 @@ def twin():
             return g
 
         @staticmethod
+        def div_small_mismatches(dmax):
+            lib.twin_div_small_mismatches.restype = ctypes.c_long
+            return int(lib.twin_div_small_mismatches(int(dmax)))
+
+        @staticmethod
         def u8_edges(x):
             x = f32(x).ravel()
             unit = np.empty(256, np.float32)

@@ -166,3 +166,8 @@ def test_layer_binary_form_on_ties_and_out_of_range_inputs(twin, seed):
         out, _ = twin.layer(1, img.numpy(), mask.float().numpy(), L.numpy(), R.numpy(), Hk.numpy(), binary=binary)
         assert max_err(out, r64.numpy()) <= 1.5 * noise + 1e-6, binary
         assert max_err(out, ref.numpy()) <= 3e-5, binary
+
+
+def test_coordinate_division_is_exact(twin):
+    """cat_coords divides column by width (model.py:487-497); the kernels use a corrected reciprocal multiply."""
+    assert twin.div_small_mismatches(8192) == 0

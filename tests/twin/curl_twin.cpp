@@ -318,4 +318,13 @@ int twin_u8_edges(float* unit256, const float* x, unsigned char* q, long n) {
   for (long i = 0; i < n; ++i) q[i] = (unsigned char)curlm::unit_to_u8(x[i]);
   return 0;
 }
+// number of (n, d) with 0 <= n < d <= dmax where div_small differs from the IEEE division
+long twin_div_small_mismatches(int dmax) {
+  long bad = 0;
+  for (int d = 1; d <= dmax; ++d) {
+    const float fd = (float)d, rd = 1.0f / fd;
+    for (int n = 0; n < d; ++n) bad += curlm::div_small((float)n, fd, rd) != (float)n / fd;
+  }
+  return bad;
+}
 }
