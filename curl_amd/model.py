@@ -14,6 +14,7 @@ class _CurlLayerFn(torch.autograd.Function):
     """Autograd node around the fused forward/backward kernels."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # under autocast: float32 in, autocast off
     def forward(ctx, img, mask, L, R, H):
         out, reg = ops.curl_layer_forward(img, mask, L, R, H)
         ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous())
@@ -21,6 +22,7 @@ class _CurlLayerFn(torch.autograd.Function):
         return out, reg
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out, grad_reg):
         img, L, R, H = ctx.saved_tensors
         need_img = ctx.needs_input_grad[0]
@@ -186,12 +188,14 @@ class _TriSpaceFn(torch.autograd.Function):
     """Autograd node around the fused polynomial kernels: gradient w.r.t. the coefficients only."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, img, coeffs, residual_only):
         ctx.save_for_backward(img, coeffs)
         ctx.residual_only = residual_only
         return ops.trispace_forward(img, coeffs, residual_only=residual_only)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         img, coeffs = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
@@ -307,6 +311,7 @@ class _LossTermsFn(torch.autograd.Function):
     """(pred, target, mask) -> (rgb_l1, cosine, lab_l1, hsv_l1, L_pred, L_target) as in model.py:89-109."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, pred, target, mask):
         sums, Lp, Lt = ops.loss_term_sums(pred, target, mask)
         s = sums.sum(0)
@@ -321,6 +326,7 @@ class _LossTermsFn(torch.autograd.Function):
         return rgb.to(f), cosine.to(f), lab.to(f), hsv.to(f), Lp, Lt
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_rgb, g_cos, g_lab, g_hsv, g_Lp, _g_Lt):
         pred, target, unmasked = ctx.saved_tensors
         w = torch.stack((g_rgb.double() / unmasked, -g_cos.double() / ctx.n, g_lab.double() / unmasked,
