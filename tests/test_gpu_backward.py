@@ -269,3 +269,59 @@ def test_train_driver_checkpoint_resume(dev, tmp_path):
     assert [e["epoch"] for e in res2["epochs"]] == [2]
     assert np.isfinite(res2["epochs"][0]["train_loss"])
     assert abs(res2["epochs"][0]["lr"] - res["epochs"][1]["lr"]) <= 1e-12  # the scheduler state came back too
+
+
+def test_autograd_nodes_under_autocast(dev):
+    """torch.autocast around the encoder: the HIP nodes cast their inputs back to float32 (custom_fwd) and the
+    parameter gradients arrive finite in the parameters' own dtype."""
+    from curl_amd import model as M
+    torch.manual_seed(5)
+    img = torch.rand(2, 3, 64, 64, device=dev)
+    mask = torch.rand(2, 1, 64, 64, device=dev) > 0.2
+    tgt = torch.rand(2, 3, 64, 64, device=dev)
+    crit = M.CURLLoss().to(dev)
+    for net in (M.TriSpaceRegNet(spatial=True, backbone=M.CurveEncoder(1, width=0.25, num_features=1024)),
+                M.GCURLNet(backbone=M.CurveEncoder(160, width=0.25))):
+        net = net.to(dev).to(memory_format=torch.channels_last).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(img, mask)
+            out = out[0] if isinstance(out, tuple) else out
+        assert out.dtype == torch.float32
+        loss = crit(out, tgt, mask)
+        loss.backward()
+        grads = [p.grad for p in net.parameters() if p.grad is not None]
+        assert grads and all(g.dtype == torch.float32 and torch.isfinite(g).all() for g in grads)
+
+
+def test_entry_points_are_reentrant_across_threads_and_streams(ops, dev):
+    """nn.DataParallel-style callers drive forward from several host threads at once.  Four threads,
+    each on its own stream and its own inputs, must get what a serial call gets."""
+    import threading
+    g = torch.Generator().manual_seed(17)
+    jobs = []
+    for t in range(4):
+        img = torch.rand(2, 3, 40 + t, 64, generator=g).to(dev)
+        L, R, H = (torch.randn(2, n, generator=g).mul(0.1).to(dev) for n in (48, 48, 64))
+        jobs.append((img, L, R, H, ops.curl_layer_forward(img, None, L, R, H)[0].clone()))
+    torch.cuda.synchronize()
+    results, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    out, _ = ops.curl_layer_forward(*jobs[i][:1], None, *jobs[i][1:4])
+                s.synchronize()
+            results[i] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for i in range(4):
+        assert torch.equal(results[i], jobs[i][4])
