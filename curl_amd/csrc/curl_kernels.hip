@@ -1028,6 +1028,72 @@ __global__ __launch_bounds__(256, 2) void trispace_bwd_px_kernel(const float* im
       }
     }
 }
+// pass 1 for the spatial form, row-tiled like OpTriSpaceRows: the forward recompute runs on the row's collapsed
+// 70-coefficient polynomials (69 FMAs per output instead of 125).  grid.x = blocks per row x rows.
+__global__ __launch_bounds__(256, 2) void trispace_bwd_px_rows_kernel(const float* img, const float* coeffs, const float* gout,
+                                                                      float* pxbuf, unsigned HW, unsigned W, unsigned H,
+                                                                      unsigned units, unsigned segs, int residual_only,
+                                                                      int vec_ok) {
+  constexpr int NC4 = PolyEval<4>::kCoeffs, NC5 = PolyEval<5>::kCoeffs, N = TRI_BWD_N;
+  typedef float VT __attribute__((ext_vector_type(N)));
+  __shared__ float s_coef[9 * NC4];
+  const unsigned b = blockIdx.y, row = blockIdx.x / segs, seg = blockIdx.x - row * segs;
+  {
+    const float* table = coeffs + (size_t)b * 9 * NC5;
+    const float y = (float)row / (float)H;
+    for (unsigned i = threadIdx.x; i < 9u * NC4; i += blockDim.x) {
+      unsigned q = i / NC4, pos = i - q * NC4;
+      s_coef[i] = collapse_coef(table + q * NC5, (int)pos, y);
+    }
+  }
+  __syncthreads();
+  const unsigned u = seg * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const unsigned col0 = u * N, i0 = row * W + col0;
+  const float* pi = img + (size_t)b * 3 * HW;
+  const float* pg = gout + (size_t)b * 3 * HW;
+  PxN<N> in, g;
+  float xw[N], yh[N];
+  if (vec_ok) {  // W % N == 0 and planes aligned to the vector: col0 + N - 1 < W
+    auto unpack = [](float (&d)[N], const float* p) {
+      VT t = *(const VT*)p;
+#pragma unroll
+      for (int k = 0; k < N; ++k) d[k] = t[k];
+    };
+    unpack(in.c0, pi + i0), unpack(in.c1, pi + HW + i0), unpack(in.c2, pi + 2 * (size_t)HW + i0);
+    unpack(g.c0, pg + i0), unpack(g.c1, pg + HW + i0), unpack(g.c2, pg + 2 * (size_t)HW + i0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      unsigned i = row * W + min(col0 + k, W - 1);
+      in.c0[k] = pi[i], in.c1[k] = pi[HW + i], in.c2[k] = pi[2 * (size_t)HW + i];
+      g.c0[k] = pg[i], g.c1[k] = pg[HW + i], g.c2[k] = pg[2 * (size_t)HW + i];
+    }
+  }
+  const float fW = (float)W, rW = 1.0f / fW;
+#pragma unroll
+  for (int k = 0; k < N; ++k) xw[k] = div_small((float)(col0 + k), fW, rW), yh[k] = 0.0f;
+  float vars[3][3][N], gP[3][3][N];
+  trispace_bwd_n<4, N, true>(in, xw, yh, s_coef, g, residual_only != 0, vars, gP);
+  float* q = pxbuf + (size_t)b * 18 * HW;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float* qv = q + (size_t)(s * 3 + c) * HW + i0;
+      float* qg = q + (size_t)(9 + s * 3 + c) * HW + i0;
+      if (vec_ok) {
+        VT tv, tg;
+#pragma unroll
+        for (int k = 0; k < N; ++k) tv[k] = vars[s][c][k], tg[k] = gP[s][c][k];
+        *(VT*)qv = tv, *(VT*)qg = tg;
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (col0 + k < W) qv[k] = vars[s][c][k], qg[k] = gP[s][c][k];
+      }
+    }
+}
 // wave-wide sum in 6 DPP adds (VALU rate; __shfl_xor compiles to ds_bpermute + a full wait each): the row's 16
 // lanes by quad_perm / half-mirror / mirror, then row_bcast15 and row_bcast31.  The total is in lane 63.
 template <int CTRL, int ROW_MASK>
@@ -1554,8 +1620,21 @@ static hipError_t launch_trispace_bwd(const float* img, const float* coeffs, con
   const unsigned va = 4 * TRI_BWD_N;
   int vec_ok = (HW % TRI_BWD_N == 0) && ((uintptr_t)img % va == 0) && ((uintptr_t)gout % va == 0) && ((uintptr_t)pxbuf % va == 0);
   unsigned threads = (HW + TRI_BWD_N - 1) / TRI_BWD_N;
-  hipLaunchKernelGGL(trispace_bwd_px_kernel<V>, dim3((threads + 255u) / 256u, (unsigned)B), dim3(256), 0, s, img, coeffs,
-                     gout, pxbuf, HW, (unsigned)W, (float)W, (float)H, residual_only, vec_ok);
+  if constexpr (V == 5) {
+    // row tiles (see make_row_geometry): block = the multiple of 64 lanes that wastes the fewest at the row end
+    int row_vec_ok = vec_ok && (W % TRI_BWD_N == 0);
+    unsigned units = ((unsigned)W + TRI_BWD_N - 1) / TRI_BWD_N, best_t = 64, best_waste = ~0u;
+    for (unsigned t = 64; t <= 256; t += 64) {
+      unsigned sg = (units + t - 1) / t, waste = sg * t - units;
+      if (waste <= best_waste) best_waste = waste, best_t = t;
+    }
+    unsigned segs = (units + best_t - 1) / best_t;
+    hipLaunchKernelGGL(trispace_bwd_px_rows_kernel, dim3(segs * (unsigned)H, (unsigned)B), dim3(best_t), 0, s, img, coeffs, gout,
+                       pxbuf, HW, (unsigned)W, (unsigned)H, units, segs, residual_only, row_vec_ok);
+  } else {
+    hipLaunchKernelGGL(trispace_bwd_px_kernel<V>, dim3((threads + 255u) / 256u, (unsigned)B), dim3(256), 0, s, img, coeffs,
+                       gout, pxbuf, HW, (unsigned)W, (float)W, (float)H, residual_only, vec_ok);
+  }
   CoefGradArgs a{pxbuf, partial, HW, (unsigned)W, tiles, ppt, (unsigned)B * 3u * tiles, 256u / (unsigned)W, 256u % (unsigned)W,
                  (float)W, (float)H};
   hipLaunchKernelGGL(trispace_coef_grad_kernel<V>, dim3((a.items + 7u) / 8u * 8u * PolyEval<V>::kChunks), dim3(256), 0, s, a);
