@@ -465,9 +465,11 @@ def test_poly_layer_golden(ops, dev, golden):
     assert max_err(N(ops.poly_layer(T(g["x3"], dev), T(g["c3"], dev))), g["channel_poly_d4v3"]) <= 3e-6
 
 
-@pytest.mark.parametrize("shape", [(1, 7, 9), (2, 30, 50), (1, 64, 100)])
+@pytest.mark.parametrize("shape", [(1, 7, 9), (2, 30, 50), (1, 64, 100), (1, 5, 1500), (2, 3, 1028), (1, 2, 4100),
+                                   (1, 300, 1)])
 def test_trispace_shapes_vs_oracle(ops, dev, shape):
-    """Coordinates (x/W, y/H) must follow the pixel through scalar / float4 kernels, W % 4 != 0 included."""
+    """Coordinates (x/W, y/H) must follow the pixel through scalar / float4 kernels, W % 4 != 0 included; rows wider
+    than one block (1500 = 2 blocks of 192 lanes, 1028 = 257 float4 groups, 4100 = 5 blocks), one-pixel rows."""
     import curl_oracle as O
     B, H, W = shape
     g = torch.Generator().manual_seed(H * W)
