@@ -789,6 +789,30 @@ struct BwdArgs {
   unsigned coef_stride, n, blocks_per_image, n_blocks;
 };
 
+// wave-wide sum in 6 DPP adds (VALU rate; __shfl_xor compiles to ds_bpermute + a full wait each): the row's 16
+// lanes by quad_perm / half-mirror / mirror, then row_bcast15 and row_bcast31.  The total is in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+// stage-major over a lane's M accumulators: consecutive DPP adds are independent (no wait states between them)
+template <int CTRL, int ROW_MASK, int R, int M>
+__device__ __forceinline__ void dpp_add_all(float (&x)[R][M]) {
+#pragma unroll
+  for (int o = 0; o < R; ++o)
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[o][j] = dpp_add<CTRL, ROW_MASK>(x[o][j]);
+  CURL_FENCE();
+}
+template <int R, int M>
+__device__ __forceinline__ void wave_sum_lane63(float (&x)[R][M]) {
+  dpp_add_all<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  dpp_add_all<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  dpp_add_all<0x141, 0xF>(x);  // row_half_mirror
+  dpp_add_all<0x140, 0xF>(x);  // row_mirror: every lane of a row holds the row's sum
+  dpp_add_all<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  dpp_add_all<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
+}
 // One tile per block, like the forward.  Per-pixel reverse mode (curl_math_bwd.h) recomputes the forward
 // chain in registers; the 20 per-image curve sums are reduced wave -> LDS -> one row of `partial` per block
 // (no float atomics: the second pass sums the rows in a fixed order in float64, so results are reproducible).
@@ -843,18 +867,15 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(BwdArgs a) {
     q0[plane + i] = y1;
     q0[2 * plane + i] = y2;
   }
-  // wave64 butterfly, then the 4 waves through LDS
+  // wave sum by DPP (total in lane 63), then the 4 waves through LDS
+  float accw[1][BWD_NACC];
 #pragma unroll
-  for (int c = 0; c < BWD_NACC; ++c) {
-    float v = acc[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    acc[c] = v;
-  }
+  for (int c = 0; c < BWD_NACC; ++c) accw[0][c] = acc[c];
+  wave_sum_lane63(accw);
   const int wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-  if (lane_id == 0) {
+  if (lane_id == 63) {
 #pragma unroll
-    for (int c = 0; c < BWD_NACC; ++c) sPart[wave][c] = acc[c];
+    for (int c = 0; c < BWD_NACC; ++c) sPart[wave][c] = accw[0][c];
   }
   __syncthreads();
   if (threadIdx.x < BWD_NACC) {
@@ -1093,30 +1114,6 @@ __global__ __launch_bounds__(256, 2) void trispace_bwd_px_rows_kernel(const floa
           if (col0 + k < W) qv[k] = vars[s][c][k], qg[k] = gP[s][c][k];
       }
     }
-}
-// wave-wide sum in 6 DPP adds (VALU rate; __shfl_xor compiles to ds_bpermute + a full wait each): the row's 16
-// lanes by quad_perm / half-mirror / mirror, then row_bcast15 and row_bcast31.  The total is in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float x) {
-  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
-}
-// stage-major over a lane's M accumulators: consecutive DPP adds are independent (no wait states between them)
-template <int CTRL, int ROW_MASK, int R, int M>
-__device__ __forceinline__ void dpp_add_all(float (&x)[R][M]) {
-#pragma unroll
-  for (int o = 0; o < R; ++o)
-#pragma unroll
-    for (int j = 0; j < M; ++j) x[o][j] = dpp_add<CTRL, ROW_MASK>(x[o][j]);
-  CURL_FENCE();
-}
-template <int R, int M>
-__device__ __forceinline__ void wave_sum_lane63(float (&x)[R][M]) {
-  dpp_add_all<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
-  dpp_add_all<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
-  dpp_add_all<0x141, 0xF>(x);  // row_half_mirror
-  dpp_add_all<0x140, 0xF>(x);  // row_mirror: every lane of a row holds the row's sum
-  dpp_add_all<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
-  dpp_add_all<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
 }
 // pass 2: block (tile of 256*ppt pixels; space s and monomial chunk C; image b) accumulates g_P[s][o] * m_t in
 // registers, reduces over the block, writes one row of partials.

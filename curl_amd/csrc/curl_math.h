@@ -115,6 +115,13 @@ CURL_HD float blend(int mask, float a, float b) {  // mask ? a : b, bit by bit
 #endif
 }
 CURL_HD float keep_if(int mask, float a) { return i2f(mask & f2i(a)); }                             // mask ? a : +0
+CURL_HD float drop_if2(int m0, int m1, float a) {                                                   // (m0 | m1) ? +0 : a
+#if defined(__HIP_DEVICE_COMPILE__)
+  return i2f(__builtin_amdgcn_bitop3_b32(m0, m1, f2i(a), 0x02));  // ~m0 & ~m1 & a, one instruction
+#else
+  return i2f(~m0 & ~m1 & f2i(a));
+#endif
+}
 CURL_HD float drop_if(int mask, float a) {                                                          // mask ? +0 : a
 #if defined(__HIP_DEVICE_COMPILE__)
   return i2f(__builtin_amdgcn_bitop3_b32(mask, f2i(a), f2i(a), 0x0C));  // ~mask & a, one instruction

@@ -18,13 +18,22 @@
 
 namespace curlm {
 
-CURL_HD float pass01(float pre) { return (pre >= 0.0f && pre <= 1.0f) ? 1.0f : 0.0f; }
-CURL_HD float pass_range(float x, float lo, float hi) { return (x >= lo && x <= hi) ? 1.0f : 0.0f; }
+// torch.clamp's gradient gate, lo <= x <= hi (boundaries included), as a bit mask built from sign bits like the
+// forward's selects (no v_cmp / v_cndmask): x - lo and hi - x are both non-negative exactly inside the range.
+// "+ 0.0f" turns a -0 difference (x = -0, lo = 0) into +0 so that the boundary passes, as it does in torch.
+CURL_HD int range_mask(float x, float lo, float hi) { return ~(neg_mask((x - lo) + 0.0f) | neg_mask(hi - x)); }
+CURL_HD int mask01(float x) { return range_mask(x, 0.0f, 1.0f); }
+CURL_HD float gate01(float g, float pre) {  // g * [0 <= pre <= 1]: two subtractions, two shifts, one bitop3
+  return drop_if2(neg_mask(pre + 0.0f), neg_mask(1.0f - pre), g);
+}
+CURL_HD float pass01(float pre) { return keep_if(mask01(pre), 1.0f); }
+CURL_HD float pass_range(float x, float lo, float hi) { return keep_if(range_mask(x, lo, hi), 1.0f); }
+CURL_HD int ge_mask(float a, float b) { return ~neg_mask(a - b); }  // a >= b (finite a, b)
 
 // y = clamp01(xo * (a + b*xi)), xi != xo.  Given gy: accumulates P, Q; returns g_xo, adds to g_xi.
 CURL_HD void curve_bwd_cross(float xo, float xi, Affine k, float gy, float& g_xo, float& g_xi, float& P, float& Q) {
   float s = fmaf(k.b, xi, k.a);
-  float g_pre = gy * pass01(xo * s);
+  float g_pre = gate01(gy, xo * s);
   float g_s = g_pre * xo;
   g_xo = g_pre * s;
   g_xi += g_s * k.b;
@@ -34,7 +43,7 @@ CURL_HD void curve_bwd_cross(float xo, float xi, Affine k, float gy, float& g_xo
 // y = clamp01(x * (a + b*x)).  Returns g_x.
 CURL_HD float curve_bwd_self(float x, Affine k, float gy, float& P, float& Q) {
   float s = fmaf(k.b, x, k.a);
-  float g_pre = gy * pass01(x * s);
+  float g_pre = gate01(gy, x * s);
   float g_s = g_pre * x;
   P += g_s;
   Q += g_s * x;
@@ -47,8 +56,8 @@ CURL_HD Px adjust3_bwd(Px p, const Affine* k, Px g, float* P, float* Q) {
   Px gi;
   gi.c0 = curve_bwd_self(p.c0, k[0], g.c0, P[0], Q[0]);
   float c1 = clamp01(p.c1), c2 = clamp01(p.c2);
-  gi.c1 = curve_bwd_self(c1, k[1], g.c1, P[1], Q[1]) * pass01(p.c1);
-  gi.c2 = curve_bwd_self(c2, k[2], g.c2, P[2], Q[2]) * pass01(p.c2);
+  gi.c1 = gate01(curve_bwd_self(c1, k[1], g.c1, P[1], Q[1]), p.c1);
+  gi.c2 = gate01(curve_bwd_self(c2, k[2], g.c2, P[2], Q[2]), p.c2);
   return gi;
 }
 
@@ -58,10 +67,10 @@ CURL_HD Px rgb2lab_bwd(Px p, Px g) {
   for (int c = 0; c < 3; ++c) {
     float u = fmaf(x[c], kInv1055, (float)(0.055 / 1.055));
     float gam = pow_gamma(u);
-    bool lo = x[c] <= kSrgbThr;
-    lin[c] = lo ? x[c] * kInv1292 : gam;
+    int hi = neg_mask(kSrgbThr - x[c]);  // x > threshold: the power branch
+    lin[c] = blend(hi, gam, x[c] * kInv1292);
     // d/dx ((x+0.055)/1.055)^2.4 = 2.4/1.055 * u^1.4 = 2.4/1.055 * gam/u
-    dlin[c] = lo ? kInv1292 : ((float)2.4 * kInv1055) * gam * rcp_refined(u);
+    dlin[c] = blend(hi, ((float)2.4 * kInv1055) * gam * hw_rcp(u), kInv1292);
   }
   const float M[3][3] = {{0.412453f * kInvXn, 0.357580f * kInvXn, 0.180423f * kInvXn},
                          {0.212671f, 0.715160f, 0.072169f},
@@ -69,9 +78,8 @@ CURL_HD Px rgb2lab_bwd(Px p, Px g) {
   float t[3], df[3];
   for (int r = 0; r < 3; ++r) {
     t[r] = fmaf(M[r][2], lin[2], fmaf(M[r][1], lin[1], M[r][0] * lin[0]));
-    bool lo = t[r] <= kEps3;
     float f = cbrt_pos(t[r]);
-    df[r] = lo ? kInv3Eps2 : kThird * f * rcp_refined(t[r]);  // (1/3) t^(-2/3) = f/(3t)
+    df[r] = blend(neg_mask(kEps3 - t[r]), kThird * f * hw_rcp(t[r]), kInv3Eps2);  // (1/3) t^(-2/3) = f/(3t)
   }
   // L = 1.16 fy - 0.16 ; a = (fx - fy) ka + 0.5 ; b = (fy - fz) kb + 0.5
   const float ka = (float)(500.0 / 220.0), kb = (float)(200.0 / 220.0);
@@ -95,9 +103,10 @@ CURL_HD Px lab2rgb_bwd(Px p, Px g) {
   float fz = fmaf(p.c2, cb, fy + (float)(110.0 / 200.0));
   float f[3] = {fx, fy, fz}, X[3], dX[3];
   for (int i = 0; i < 3; ++i) {
-    bool lo = f[i] <= kEps;
-    X[i] = lo ? fmaf(f[i], k3Eps2, -(k3Eps2 * k4_29)) : f[i] * f[i] * f[i];
-    dX[i] = lo ? k3Eps2 : 3.0f * f[i] * f[i];
+    int hi = neg_mask(kEps - f[i]);
+    float f2 = f[i] * f[i];
+    X[i] = blend(hi, f2 * f[i], fmaf(f[i], k3Eps2, -(k3Eps2 * k4_29)));
+    dX[i] = blend(hi, 3.0f * f2, k3Eps2);
   }
   const float M[3][3] = {{3.2404542f * kXn, -1.5371385f, -0.4985314f * kZn},
                          {-0.9692660f * kXn, 1.8760108f, 0.0415560f * kZn},
@@ -105,10 +114,9 @@ CURL_HD Px lab2rgb_bwd(Px p, Px g) {
   float gv[3], go[3] = {g.c0, g.c1, g.c2};
   for (int r = 0; r < 3; ++r) {
     float v = fmaf(M[r][2], X[2], fmaf(M[r][1], X[1], M[r][0] * X[0]));
-    bool lo = v <= kLinThr;
     float pw = pow_inv_gamma(v);
     // d/dv (1.055 v^(1/2.4) - 0.055) = 1.055/2.4 * v^(1/2.4 - 1) = 1.055/2.4 * pw / v
-    float d = lo ? 12.92f : (1.055f * kInvGamma) * pw * rcp_refined(v);
+    float d = blend(neg_mask(kLinThr - v), (1.055f * kInvGamma) * pw * hw_rcp(v), 12.92f);
     gv[r] = go[r] * d;
   }
   float gX[3];
@@ -123,42 +131,44 @@ CURL_HD Px lab2rgb_bwd(Px p, Px g) {
 
 // ---- RGB -> HSV
 CURL_HD Px rgb2hsv_bwd(Px p, Px g) {
-  float q[3] = {p.c0, p.c1, p.c2}, c[3], pin[3];
+  float q[3] = {p.c0, p.c1, p.c2}, c[3];
+  int pin[3];
   for (int i = 0; i < 3; ++i) {
     c[i] = clampf(q[i], kHsvFloor, 1.0f);
-    pin[i] = pass_range(q[i], kHsvFloor, 1.0f);
+    pin[i] = range_mask(q[i], kHsvFloor, 1.0f);
   }
   float r = c[0], gg = c[1], b = c[2];
   float mx = fmaxf(r, fmaxf(gg, b)), mn = fminf(r, fminf(gg, b));
-  int imax = (r >= gg && r >= b) ? 0 : (gg >= b ? 1 : 2);  // first index attaining the max
-  int imin = (r <= gg && r <= b) ? 0 : (gg <= b ? 1 : 2);
-  float df = mx - mn;
-  bool flat = (df == 0.0f);
-  float dfi = flat ? 0.0f : rcp_refined(df);
-  float mxi = rcp_refined(mx);
-  float er = (r == mx) ? 1.0f : 0.0f, eg = (gg == mx) ? 1.0f : 0.0f, eb = (b == mx) ? 1.0f : 0.0f;
-  float Nn = er * (gg - b) + eg * (b - r) + eb * (r - gg);
-  float h6 = flat ? 0.0f : (er * ((gg - b) * dfi) + eg * fmaf(b - r, dfi, 2.0f)) + eb * fmaf(r - gg, dfi, 4.0f);
-  float h = (h6 + (h6 < 0.0f ? 6.0f : 0.0f)) * (float)(1.0 / 6.0);
+  // first index attaining the max / the min (torch.max/min over dim=1), as masks
+  int max0 = ge_mask(r, gg) & ge_mask(r, b), max1 = ~max0 & ge_mask(gg, b), max2 = ~(max0 | max1);
+  int min0 = ge_mask(gg, r) & ge_mask(b, r), min1 = ~min0 & ge_mask(b, gg), min2 = ~(min0 | min1);
+  float nd = mn - mx;                 // -(max - min): sign set iff the pixel is not flat
+  int live = neg_mask(nd);
+  float df = -nd;
+  float dfi = keep_if(live, hw_rcp(df));
+  float mxi = hw_rcp(mx);
+  // [c == mx]: c - mx is negative exactly when c is NOT the maximum
+  int ner = neg_mask(r - mx), neg_ = neg_mask(gg - mx), neb = neg_mask(b - mx);
+  float er = drop_if(ner, 1.0f), eg = drop_if(neg_, 1.0f), eb = drop_if(neb, 1.0f);
+  float Nn = drop_if(ner, gg - b) + drop_if(neg_, b - r) + drop_if(neb, r - gg);
+  float h6 = keep_if(live, (drop_if(ner, (gg - b) * dfi) + drop_if(neg_, fmaf(b - r, dfi, 2.0f))) +
+                               drop_if(neb, fmaf(r - gg, dfi, 4.0f)));
+  float h = (h6 + keep_if(neg_mask(h6), 6.0f)) * (float)(1.0 / 6.0);
   float s = df * mxi;
   // output clamp (colors.py:240)
-  float g_h = g.c0 * pass_range(h, kHsvFloor, 1.0f);
-  float g_s = g.c1 * pass_range(s, kHsvFloor, 1.0f);
-  float g_v = g.c2 * pass_range(mx, kHsvFloor, 1.0f);
-  float g_h6 = flat ? 0.0f : g_h * (float)(1.0 / 6.0);
+  float g_h = keep_if(range_mask(h, kHsvFloor, 1.0f), g.c0);
+  float g_s = keep_if(range_mask(s, kHsvFloor, 1.0f), g.c1);
+  float g_v = keep_if(range_mask(mx, kHsvFloor, 1.0f), g.c2);
+  float g_h6 = keep_if(live, g_h * (float)(1.0 / 6.0));
   float g_N = g_h6 * dfi;
   float g_df = -(g_h6 * Nn) * dfi * dfi + g_s * mxi;
   float g_mx = -(g_s * df) * mxi * mxi + g_v + g_df;
   float g_mn = -g_df;
   float gc[3];
-  gc[0] = g_N * (eb - eg);
-  gc[1] = g_N * (er - eb);
-  gc[2] = g_N * (eg - er);
-  for (int i = 0; i < 3; ++i) {
-    if (i == imax) gc[i] += g_mx;
-    if (i == imin) gc[i] += g_mn;
-  }
-  Px gi{gc[0] * pin[0], gc[1] * pin[1], gc[2] * pin[2]};
+  gc[0] = g_N * (eb - eg) + keep_if(max0, g_mx) + keep_if(min0, g_mn);
+  gc[1] = g_N * (er - eb) + keep_if(max1, g_mx) + keep_if(min1, g_mn);
+  gc[2] = g_N * (eg - er) + keep_if(max2, g_mx) + keep_if(min2, g_mn);
+  Px gi{keep_if(pin[0], gc[0]), keep_if(pin[1], gc[1]), keep_if(pin[2], gc[2])};
   return gi;
 }
 
@@ -175,7 +185,7 @@ CURL_HD Px adjust_hsv4_bwd(Px p, const Affine* k, Px g, float* P, float* Q) {
   float g_sc, g_h1 = g.c0;
   curve_bwd_cross(sc, h1, k[1], g_s1, g_sc, g_h1, P[1], Q[1]);
   float g_h = curve_bwd_self(h, k[0], g_h1, P[0], Q[0]);
-  Px gi{g_h, g_sc * pass01(p.c1), g_vc * pass01(p.c2)};
+  Px gi{g_h, gate01(g_sc, p.c1), gate01(g_vc, p.c2)};
   return gi;
 }
 
@@ -190,7 +200,7 @@ CURL_HD Px hsv2rgb_bwd(Px p, Px g) {
   float r = fmaf(R4, d, fmaf(R1, -d, vv));
   float gn = fmaf(G3, -d, fmaf(G0, d, q));
   float b = fmaf(B5, -d, fmaf(B2, d, q));
-  float gr = g.c0 * pass01(r), gg = g.c1 * pass01(gn), gb = g.c2 * pass01(b);
+  float gr = gate01(g.c0, r), gg = gate01(g.c1, gn), gb = gate01(g.c2, b);
   float g_vv = gr;
   float g_q = gg + gb;
   float g_d = gr * (R4 - R1) + gg * (G0 - G3) + gb * (B2 - B5);
@@ -202,7 +212,7 @@ CURL_HD Px hsv2rgb_bwd(Px p, Px g) {
   // q = vv (1 - ss)
   g_vv += g_q * (1.0f - ss);
   float g_ss = -g_q * vv;
-  Px gi{6.0f * g_H * pass01(p.c0), g_ss * pass01(p.c1), g_vv * pass01(p.c2)};
+  Px gi{gate01(6.0f * g_H, p.c0), gate01(g_ss, p.c1), gate01(g_vv, p.c2)};
   return gi;
 }
 
@@ -220,8 +230,8 @@ CURL_HD Px curl_layer_bwd(Px in, float m, const LayerCoef& k, Px gout, float* P,
   Px hsv2{hsv1.c0 * m, hsv1.c1 * m, hsv1.c2 * m};
   Px res = hsv2rgb(hsv2);
   // out = clamp01(in + res) * m   (model.py:170)
-  Px g_pre{gout.c0 * m * pass01(in.c0 + res.c0), gout.c1 * m * pass01(in.c1 + res.c1),
-           gout.c2 * m * pass01(in.c2 + res.c2)};
+  Px g_pre{gate01(gout.c0 * m, in.c0 + res.c0), gate01(gout.c1 * m, in.c1 + res.c1),
+           gate01(gout.c2 * m, in.c2 + res.c2)};
   Px g = hsv2rgb_bwd(hsv2, g_pre);
   g = Px{g.c0 * m, g.c1 * m, g.c2 * m};
   g = adjust_hsv4_bwd(hsv0, k.hsv, g, P + 6, Q + 6);

@@ -26,7 +26,7 @@ def bind(path):
 def main():
     pa, pb = sys.argv[1], sys.argv[2]
     what = sys.argv[3] if len(sys.argv) > 3 else "layer"
-    B, H, W = int(os.environ.get("B", 32)), 1000, 1500
+    B, H, W = int(os.environ.get("B", 32)), int(os.environ.get("H", 1000)), int(os.environ.get("W", 1500))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     imgs = [torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
@@ -40,6 +40,11 @@ def main():
     ws = torch.empty(nb // 4, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     cnt = [0]
+    gout = torch.rand(B, 3, H, W, device=dev) if what == "layer_bwd" else None
+    gin = torch.empty_like(out)
+    gL, gR, gH = torch.empty_like(L), torch.empty_like(R), torch.empty_like(Hk)
+    sb = libs["A"].curl_layer_bwd_scratch_bytes(B, H, W)
+    scratch = torch.empty(max(4, sb) // 4, device=dev)
 
     def run(lib, flags):
         cnt[0] += 1
@@ -47,6 +52,10 @@ def main():
         if what == "layer":
             rc = lib.curl_layer_fwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
                                         out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nb, B, H, W, 16, 16, 16, flags, stream)
+        elif what == "layer_bwd":
+            rc = lib.curl_layer_bwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
+                                        gout.data_ptr(), 0, gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
+                                        ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, 0, stream)
         elif what == "lab_stage":
             rc = lib.curl_lab_stage_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                         ws.data_ptr(), nb, B, H, W, 16, flags, stream)
@@ -55,7 +64,7 @@ def main():
         assert rc == 0, rc
 
     extra = {"A": int(os.environ.get("FLAGS_A", "0"), 0), "B": int(os.environ.get("FLAGS_B", "0"), 0)}  # e.g. 0x200 = U=2
-    variants = [(k, d) for d in (0, _lib.F_DIAG_NO_MEM) for k in ("A", "B")]
+    variants = [(k, d) for d in ((0,) if what == "layer_bwd" else (0, _lib.F_DIAG_NO_MEM)) for k in ("A", "B")]
     times = {v: [] for v in variants}
     for _ in range(150):  # clock settle
         run(libs["A"], 0)
