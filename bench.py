@@ -194,8 +194,8 @@ def load_traffic(kernel_fragment):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--workload", default="layer", choices=sorted(WORKLOADS))
     ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / cpu_baseline / accuracy")
