@@ -392,6 +392,60 @@ def test_fullsize_vs_oracle_frames(ops, big):
         assert frac((ls - ls_ref.double()).abs(), 1e-5) <= 1.25 * frac((ls_ref.double() - ls64).abs(), 1e-5) + 1e-5, b
 
 
+def test_bs32_fullsize_round_trips_and_batch_independence(ops, dev):
+    """BASELINE configs[2] at its real size, 32 x 1500x1000 (48 Mpix, 576 MB per tensor): colour-space round trips
+    return the input, and the first / last image of the batch equal the same image processed alone."""
+    torch.manual_seed(32)
+    B, H, W = 32, 1000, 1500
+    img = torch.rand(B, 3, H, W, device=dev)
+    back = ops.lab2rgb(ops.rgb2lab(img))
+    # the reference's forward matrix (OpenCV, colors.py:10-12) and inverse matrix (Lindbloom, colors.py:71-73) are
+    # not exact inverses of each other: its own round trip is off by up to ~4e-5
+    assert float((back - img).abs().max()) <= 1e-4
+    del back
+    hsv_back = ops.hsv2rgb(ops.rgb2hsv(img))
+    # exact channel ties are not round-trip points of the reference: its hue terms ADD there (colors.py:221-224,
+    # r == g > b comes out as 120 degrees); among 48M random pixels a handful tie
+    r, g, b = img[:, 0], img[:, 1], img[:, 2]
+    distinct = ((r != g) & (g != b) & (r != b)).unsqueeze(1)
+    assert float(((hsv_back - img.clamp(1e-9, 1)).abs() * distinct).max()) <= 2e-6
+    assert int((~distinct).sum()) < 100
+    del hsv_back, distinct
+    L, R, Hk = (torch.randn(B, n, device=dev) * 0.1 for n in (48, 48, 64))
+    mask = torch.ones(B, 1, H, W, dtype=torch.bool, device=dev)
+    out, reg = ops.curl_layer_forward(img, mask, L, R, Hk)
+    assert out.min() >= 0 and out.max() <= 1 and torch.isfinite(out).all()
+    for b in (0, 31):
+        o1, r1 = ops.curl_layer_forward(img[b:b + 1], mask[b:b + 1], L[b:b + 1], R[b:b + 1], Hk[b:b + 1])
+        assert torch.equal(o1[0], out[b]) and torch.equal(r1[0], reg[b])
+
+
+def test_fullsize_trispace_properties(ops, dev):
+    """1500x1000 frames through the row-tiled polynomial kernel: zero coefficients give sigmoid(0) = 0.5 everywhere,
+    so the residual is one constant colour (the oracle's value for a single pixel); constant-only coefficients make
+    the result independent of position; images of a batch equal the same images processed alone."""
+    import curl_oracle as O
+    torch.manual_seed(7)
+    B, H, W = 3, 1000, 1500
+    img = torch.rand(B, 3, H, W, device=dev)
+    zero = torch.zeros(B, 3, 3, 126, device=dev)
+    res = ops.trispace_forward(img, zero, residual_only=True)
+    one = O.trispace_residual(torch.rand(1, 3, 1, 1), *(torch.zeros(1, 3, 126),) * 3)[0, :, 0, 0]
+    assert float((res - one.to(dev).view(1, 3, 1, 1)).abs().max()) <= 2e-6
+    c = torch.zeros(B, 3, 3, 126, device=dev)
+    c[..., 0] = torch.randn(B, 3, 3, device=dev)          # constant terms only
+    c[:, 0, :, 1:4] = torch.randn(B, 3, 3, device=dev) * 0.3  # RGB space: linear in the colour channels
+    out = ops.trispace_forward(img, c)
+    perm = torch.randperm(H * W, device=dev)
+    pimg = img.view(B, 3, -1)[:, :, perm].view(B, 3, H, W).contiguous()
+    pout = ops.trispace_forward(pimg, c)
+    assert torch.equal(pout.view(B, 3, -1), out.view(B, 3, -1)[:, :, perm])  # no coordinate terms: pointwise
+    full = torch.randn(B, 3, 3, 126, device=dev) * 0.2
+    out = ops.trispace_forward(img, full)
+    for b in (0, 2):
+        assert torch.equal(ops.trispace_forward(img[b:b + 1], full[b:b + 1])[0], out[b])
+
+
 def test_gcurlnet_forward(dev):
     """Encoder (stock PyTorch-ROCm) -> 160 knots -> fused HIP layer, against the oracle on the same knots."""
     import curl_oracle as O
