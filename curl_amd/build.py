@@ -8,7 +8,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "curl_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "curl_math.h"), os.path.join(os.path.dirname(HERE), "include", "curl_hip.h")]
+INCLUDE = os.path.join(os.path.dirname(HERE), "include", "curl_hip.h")
+
+
+def _deps():
+    """Everything the one translation unit reads: csrc/*.h|.hip|.inc, csrc/kernels/*.inc, the public header."""
+    out = [INCLUDE]
+    for d, _, files in os.walk(os.path.join(HERE, "csrc")):
+        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hip", ".inc"))]
+    return out
+
 OUT = os.path.join(HERE, "lib", "libcurlhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-math-errno"]
@@ -17,7 +26,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wal
 def build(force=False, verbose=False):
     """Compile curl_amd/csrc/curl_kernels.hip -> curl_amd/lib/libcurlhip.so (in-tree, so it travels with the repo)."""
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in _deps()):
         return OUT
     cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-o", OUT, SRC]
     res = subprocess.run(cmd, capture_output=True, text=True)
