@@ -55,6 +55,9 @@ SIGNATURES = {
     "curl_f32chw_to_u8hwc": (_i, [_c_f, _c_f, _i, _i, _i, _c_f]),
     "curl_psnr_scratch_bytes": (_sz, [_i, _i, _i]),
     "curl_psnr_f32": (_i, [_c_f, _c_f, _c_f, _i, _c_f, _c_f, _sz, _i, _i, _i, ctypes.c_float, _c_f]),
+    "curl_msssim_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "curl_msssim_fwd_f32": (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _i, _c_f]),
+    "curl_msssim_bwd_f32": (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _i, _c_f]),
     "curl_loss_terms_scratch_bytes": (_sz, [_i, _i, _i]),
     "curl_loss_terms_f32": (_i, [_c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _c_f]),
     "curl_loss_terms_bwd_f32": (_i, [_c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _i, _i, _i, _c_f]),

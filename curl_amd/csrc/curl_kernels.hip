@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
 #include "kernels/chain.inc"
 #include "kernels/layer_bwd.inc"
 #include "kernels/psnr.inc"
+#include "kernels/msssim.inc"
 #include "kernels/poly_bwd.inc"
 #include "kernels/loss.inc"
 #include "kernels/edges.inc"

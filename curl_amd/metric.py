@@ -25,10 +25,31 @@ class PSNRMetric(nn.Module):
         return PSNRMetric.compute_psnr(image_batchA, image_batchB, mask_batch, max_intensity=self.max_intensity)
 
 
+class _MSSSIMStatsFn(torch.autograd.Function):
+    """The five-level SSIM statistics on the HIP kernels; differentiable w.r.t. the first image."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, img1, img2, window_size):
+        ctx.save_for_backward(img1, img2)
+        ctx.window_size = window_size
+        return ops.msssim_stats(img1, img2, window_size)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_ssims, g_mcs):
+        img1, img2 = ctx.saved_tensors
+        return ops.msssim_stats_backward(img1, img2, g_ssims, g_mcs, ctx.window_size), None, None
+
+
 class MSSSIMMetric(nn.Module):
     """metric.py:75-211.  Same constructor, `compute_ssim`, `compute_msssim`, `forward` and state (the
-    `msssim_weights` parameter); the window is a buffer that follows `.to(device)`.  The 2-D Gaussian window is
-    applied as two 1-D passes (it is an outer product, metric.py:99-101): 2*ws taps per pixel instead of ws^2."""
+    `msssim_weights` parameter); the window is a buffer that follows `.to(device)`.
+    On a HIP device `compute_msssim` gets the per-level statistics from the fused kernels (ops.msssim_stats: one
+    launch per level, separable window through LDS; 4.5 ms -> 0.1 ms forward + backward at 32x1x256x256) when the
+    window fits (<= 11), the images are large enough for five levels and only the first image needs a gradient;
+    otherwise -- and always on the CPU -- the stock-torch form below, with the 2-D Gaussian window applied as two
+    1-D passes (it is an outer product, metric.py:99-101)."""
 
     def __init__(self, window_size=11, num_channel=3):
         super().__init__()
@@ -78,14 +99,21 @@ class MSSSIMMetric(nn.Module):
             raise RuntimeError('Input images must have the same shape (%s vs. %s).', img1.shape, img2.shape)
         if img1.ndim != 4:
             raise RuntimeError('Input images must have four dimensions, not %d', img1.ndim)
-        ssims, mcs = [], []
-        for _ in range(self.levels):
-            ssim, cs = self.compute_ssim(img1, img2)
-            ssims.append(ssim)
-            mcs.append(cs)
-            img1, img2 = F.avg_pool2d(img1, (2, 2)), F.avg_pool2d(img2, (2, 2))
-        ssims = (torch.stack(ssims, dim=1) + 1) / 2
-        mcs = (torch.stack(mcs, dim=1) + 1) / 2
+        fused = (img1.is_cuda and img1.dtype == torch.float32 and img2.dtype == torch.float32 and self.levels == 5
+                 and self.window_size <= 11 and self.window_size % 2 == 1 and min(img1.shape[2:]) >= 32
+                 and not (torch.is_grad_enabled() and img2.requires_grad))
+        if fused:
+            ssims, mcs = _MSSSIMStatsFn.apply(img1, img2, self.window_size)
+        else:
+            ssims, mcs = [], []
+            for _ in range(self.levels):
+                ssim, cs = self.compute_ssim(img1, img2)
+                ssims.append(ssim)
+                mcs.append(cs)
+                img1, img2 = F.avg_pool2d(img1, (2, 2)), F.avg_pool2d(img2, (2, 2))
+            ssims, mcs = torch.stack(ssims, dim=1), torch.stack(mcs, dim=1)
+        ssims = (ssims + 1) / 2
+        mcs = (mcs + 1) / 2
         w = self.msssim_weights.reshape(1, -1)
         pow1, pow2 = mcs ** w, ssims ** w
         return torch.prod(pow1[:, :-1] * pow2[:, -1].reshape(-1, 1), dim=1)

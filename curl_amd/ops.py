@@ -387,6 +387,47 @@ def curl_layer_forward_u8hwc(img_u8, mask, L, R, H, white_mask=None):
     return out, reg
 
 
+def _planes(t, name):
+    _need_device(t, name)
+    if t.dim() != 4 or t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32 [B,C,H,W], got {t.dtype} {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def msssim_stats(a, b, window_size=11):
+    """MSSSIMMetric.compute_ssim over the five pyramid levels (metric.py:120-166,185-192) in five launches.
+    a, b [B,C,H,W] -> (ssims [B,5], mcs [B,5]): per level, the per-image means of the SSIM and contrast-structure maps."""
+    lib = _lib.load()
+    a, b = _planes(a, "img1"), _planes(b, "img2")
+    if a.shape != b.shape:
+        raise RuntimeError(f"Input images must have the same shape ({tuple(a.shape)} vs. {tuple(b.shape)}).")
+    B, C, H, W = a.shape
+    nbytes = lib.curl_msssim_scratch_bytes(B, C, H, W)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+    ssims = torch.empty(B, 5, dtype=torch.float32, device=a.device)
+    mcs = torch.empty_like(ssims)
+    rc = lib.curl_msssim_fwd_f32(a.data_ptr(), b.data_ptr(), ssims.data_ptr(), mcs.data_ptr(), scratch.data_ptr(), nbytes,
+                                 B, C, H, W, window_size, _stream(a))
+    _lib.check(rc, "curl_msssim_fwd_f32")
+    return ssims, mcs
+
+
+def msssim_stats_backward(a, b, g_ssims, g_mcs, window_size=11):
+    """d loss / d a of msssim_stats, given d loss / d ssims and d loss / d mcs ([B,5] each)."""
+    lib = _lib.load()
+    a, b = _planes(a, "img1"), _planes(b, "img2")
+    B, C, H, W = a.shape
+    gs = g_ssims.to(torch.float32).contiguous()
+    gc = g_mcs.to(torch.float32).contiguous()
+    nbytes = lib.curl_msssim_scratch_bytes(B, C, H, W)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a)
+    rc = lib.curl_msssim_bwd_f32(a.data_ptr(), b.data_ptr(), gs.data_ptr(), gc.data_ptr(), grad.data_ptr(),
+                                 scratch.data_ptr(), nbytes, B, C, H, W, window_size, _stream(a))
+    _lib.check(rc, "curl_msssim_bwd_f32")
+    return grad
+
+
 def psnr_per_image(a, b, mask=None, max_intensity=1.0):
     """metric.py:35-62 per image: masked PSNR [B] (NaN where an image has no unmasked pixel or zero error -> inf)."""
     lib = _lib.load()

@@ -199,6 +199,23 @@ int curl_psnr_f32(const float* a, const float* b, const void* mask, int mask_kin
                   void* scratch, size_t scratch_bytes, int B, int H, int W, float max_intensity,
                   curl_stream_t stream);
 
+/* replaces: MSSSIMMetric.compute_ssim per pyramid level + F.avg_pool2d between levels (metric.py:120-166,
+ *           185-192) -- the term of CURLLoss.forward at model.py:103-105 and the MS-SSIM of evaluate.py.
+ * a, b: [B,C,H,W] float32 (C = 1 for the loss's L planes).  ssims, mcs: [B,5] = per level, the per-image means of
+ * the SSIM map and of the contrast-structure map; the caller finishes metric.py:194-208 ((x+1)/2, powers, product)
+ * on those ten numbers per image.  window_size odd, <= 11 (Gaussian, sigma 1.5, zero padding); H, W >= 32 (below that the
+ * reference's fifth avg_pool2d raises).
+ * One launch per level (32x32 tiles, separable window through LDS, all five blurs at once, next level written by
+ * the same block) + a fixed-order float64 reduction: deterministic.  scratch: curl_msssim_scratch_bytes, 16-aligned. */
+size_t curl_msssim_scratch_bytes(int B, int C, int H, int W);
+int curl_msssim_fwd_f32(const float* a, const float* b, float* ssims, float* mcs, void* scratch, size_t scratch_bytes,
+                        int B, int C, int H, int W, int window_size, curl_stream_t stream);
+/* replaces: autograd of the above w.r.t. `a` (the prediction; `b` is the target): g_ssims, g_mcs [B,5] are
+ * d loss / d ssims, d loss / d mcs; grad_a [B,C,H,W] is ASSIGNED.  Stateless: rebuilds the pyramids in scratch. */
+int curl_msssim_bwd_f32(const float* a, const float* b, const float* g_ssims, const float* g_mcs, float* grad_a,
+                        void* scratch, size_t scratch_bytes, int B, int C, int H, int W, int window_size,
+                        curl_stream_t stream);
+
 /* replaces: the per-pixel terms of CURLLoss.forward  model.py:89-109 (masked L1 in RGB, cosine similarity,
  *           L1 in clamped Lab, L1 on the HSV cone) in one pass over prediction and target.
  * sums [B,5] float64 (ASSIGNED), per image: sum|p-t|, sum cos_sim, sum|lab_p-lab_t|, sum|cone_p-cone_t|, sum(mask).

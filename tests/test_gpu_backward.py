@@ -325,3 +325,45 @@ def test_entry_points_are_reentrant_across_threads_and_streams(ops, dev):
     assert not errors, errors
     for i in range(4):
         assert torch.equal(results[i], jobs[i][4])
+
+
+@pytest.mark.parametrize("tag", ["loss", "rgb", "w5"])
+def test_msssim_hip_vs_reference_golden(dev, golden, tag):
+    """The fused MS-SSIM kernels (through curl_amd.metric.MSSSIMMetric on the device) against outputs and gradients of
+    the reference's own class (tests/golden/make_golden_msssim.py), and against the stock-torch route of the mirror."""
+    from curl_amd import metric, ops
+    g = golden("msssim")
+    ws, ch = (int(v) for v in g[tag + "_cfg"])
+    m = metric.MSSSIMMetric(window_size=ws, num_channel=ch).to(dev)
+    a = torch.from_numpy(g[tag + "_a"]).to(dev).requires_grad_(True)
+    b = torch.from_numpy(g[tag + "_b"]).to(dev)
+    ssims, mcs = ops.msssim_stats(a.detach(), b, ws)
+    assert np.abs(ssims[:, 0].cpu().numpy() - g[tag + "_ssim"]).max() <= 2e-6
+    assert np.abs(mcs[:, 0].cpu().numpy() - g[tag + "_cs"]).max() <= 2e-6
+    out = m(a, b)
+    assert np.abs(out.detach().cpu().numpy() - g[tag + "_out"]).max() <= 3e-6
+    (out * torch.from_numpy(g[tag + "_w"]).to(dev)).sum().backward()
+    ref = g[tag + "_grad_a"]
+    assert np.abs(a.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+    again = ops.msssim_stats(a.detach(), b, ws)
+    assert torch.equal(again[0], ssims) and torch.equal(again[1], mcs)  # fixed-order reductions
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (1, 3, 97, 131), (3, 1, 32, 35)])
+def test_msssim_hip_odd_shapes_vs_torch_route(dev, shape):
+    """Sizes that are not multiples of the 32x32 tile or of 2 (avg_pool2d floors), down to the 32-pixel minimum (below it the
+    reference's fifth pooling raises; so does this path)."""
+    from curl_amd import metric
+    torch.manual_seed(sum(shape))
+    a = torch.rand(*shape, device=dev)
+    b = (a + 0.1 * torch.randn(*shape, device=dev)).clamp(0, 1)
+    m = metric.MSSSIMMetric(window_size=11, num_channel=shape[1]).to(dev)
+    a1 = a.clone().requires_grad_(True)
+    out = m(a1, b)
+    out.sum().backward()
+    a2 = a.clone().requires_grad_(True)
+    b2 = b.clone().requires_grad_(True)  # a gradient for the second image forces the stock-torch route
+    ref = m(a2, b2)
+    ref.sum().backward()
+    assert float((out - ref).abs().max()) <= 3e-6
+    assert float((a1.grad - a2.grad).abs().max()) <= 1e-3 * float(a2.grad.abs().max())
