@@ -75,20 +75,24 @@ def forward_image(net, img, mask):
 
 @torch.no_grad()
 def evaluate(net, criterion, loader, device, world):
-    """evaluate.py:74-139 reduced to what main.py consumes: mean loss and mean masked PSNR over the split."""
+    """evaluate.py:74-139 (Evaluator.evaluate) without the image dump: mean loss, mean masked PSNR (batches whose
+    PSNR is undefined are left out of its mean, evaluate.py:111-112) and mean MS-SSIM of the masked RGB images
+    (evaluate.py:103-104: MSSSIMMetric() defaults, 3 channels, window 11), summed over ranks like its gather."""
     net.eval()
-    psnr = metric.PSNRMetric()
-    acc = torch.zeros(3, dtype=torch.float64, device=device)  # loss sum, psnr sum, batches
+    psnr, msssim = metric.PSNRMetric(), metric.MSSSIMMetric().to(device)
+    acc = torch.zeros(5, dtype=torch.float64, device=device)  # loss sum, batches, psnr sum, psnr batches, msssim sum
     for batch in loader:
         img, gt, mask = (batch[k].to(device, non_blocking=True) for k in ("input_img", "output_img", "mask"))
-        out = forward_image(net, img, mask).clamp(0, 1)
-        p = psnr(out, gt, mask)
-        acc += torch.stack((criterion(out, gt, mask).double(), (p if p is not None else torch.zeros((), device=device)).double(),
-                            torch.ones((), dtype=torch.float64, device=device)))
+        out = forward_image(net, img, mask)
+        p = psnr(gt, out, mask)
+        one = torch.ones((), dtype=torch.float64, device=device)
+        acc += torch.stack((criterion(out, gt, mask).double(), one,
+                            p.double() if p is not None else 0 * one, one if p is not None else 0 * one,
+                            msssim(gt * mask, out * mask).mean().double()))
     if world > 1:
         dist.all_reduce(acc)
     net.train()
-    return float(acc[0] / acc[2]), float(acc[1] / acc[2])
+    return float(acc[0] / acc[1]), float(acc[2] / acc[3].clamp(min=1)), float(acc[4] / acc[1])
 
 
 def main(argv=None):
@@ -182,7 +186,8 @@ def main(argv=None):
                  "train_loss": sum(t[0] for t in totals) / max(1, sum(t[1] for t in totals))}
         scheduler.step()
         if (epoch + 1) % args.valid_every == 0:                               # main.py:313-340
-            entry["valid_loss"], entry["valid_psnr"] = evaluate(net, criterion, valid_loader, device, world if ddp else 1)
+            entry["valid_loss"], entry["valid_psnr"], entry["valid_msssim"] = evaluate(net, criterion, valid_loader, device,
+                                                                                       world if ddp else 1)
             if rank == 0 and args.log_dirpath:
                 os.makedirs(args.log_dirpath, exist_ok=True)
                 path = os.path.join(args.log_dirpath, "curl_validpsnr_{}_validloss_{}_epoch_{}_model.pt".format(
