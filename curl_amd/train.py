@@ -118,7 +118,10 @@ def main(argv=None):
     ap.add_argument("--channels_last", action=argparse.BooleanOptionalAction, default=True,
                     help="NHWC memory format for the encoder's convolutions (same float32 results; measured 136 -> 85 ms "
                          "per 32x256x256 step on MI355X, 74 ms with --amp bf16)")
+    ap.add_argument("--miopen_benchmark", action=argparse.BooleanOptionalAction, default=False,
+                    help="torch.backends.cudnn.benchmark: let MIOpen time its solvers per convolution shape")
     args = ap.parse_args(argv)
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     if args.training_img_dirpath != "synthetic":
         raise NotImplementedError("only --training_img_dirpath synthetic: the reference's data.py (torchvision, "
                                   "Adobe-5k-DPE folders) is outside this path; plug any Dataset with its item keys")
