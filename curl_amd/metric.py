@@ -46,7 +46,8 @@ class MSSSIMMetric(nn.Module):
     """metric.py:75-211.  Same constructor, `compute_ssim`, `compute_msssim`, `forward` and state (the
     `msssim_weights` parameter); the window is a buffer that follows `.to(device)`.
     On a HIP device `compute_msssim` gets the per-level statistics from the fused kernels (ops.msssim_stats: one
-    launch per level, separable window through LDS; 4.5 ms -> 0.1 ms forward + backward at 32x1x256x256) when the
+    launch per level, separable window through LDS; the whole CURLLoss forward + backward went from 4.8 to 0.83 ms at
+    32x256x256) when the
     window fits (<= 11), the images are large enough for five levels and only the first image needs a gradient;
     otherwise -- and always on the CPU -- the stock-torch form below, with the 2-D Gaussian window applied as two
     1-D passes (it is an outer product, metric.py:99-101)."""
