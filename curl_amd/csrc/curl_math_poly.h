@@ -15,22 +15,30 @@
 namespace curlm {
 
 #if defined(__HIP_DEVICE_COMPILE__)
-CURL_HD curl_f2 poly_fma(curl_f2 a, curl_f2 v, float c) { return __builtin_elementwise_fma(a, v, splat2(c)); }
 CURL_HD curl_f2 poly_fmav(curl_f2 a, curl_f2 v, curl_f2 q) { return __builtin_elementwise_fma(a, v, q); }
-CURL_HD void poly_splat(curl_f2& d, float c) { d = splat2(c); }
 #endif
-CURL_HD float poly_fma(float a, float v, float c) { return fmaf(a, v, c); }
 CURL_HD float poly_fmav(float a, float v, float q) { return fmaf(a, v, q); }
-CURL_HD void poly_splat(float& d, float c) { d = c; }
 
+// A coefficient as the evaluator's value type F.  seq(): from the consumption-order table; ref(): from the
+// reference-order table.  (Storing every coefficient twice, so that the packed type reads {c, c} as one 8-byte
+// operand, removes the 170 v_mov per 4 pixels that broadcast odd halves -- and doubles the LDS reads, which the
+// four SIMDs of a CU share: measured 8 % slower.)
 template <class F>
-CURL_HD F poly_make(float c) {
-  F d;
-  poly_splat(d, c);
-  return d;
-}
-#define CURL_POLY_SPLAT(c) poly_make<F>(c)
-#define CURL_POLY_FMA(a, v, c) poly_fma(a, v, c)
+struct PolyCoef;
+template <>
+struct PolyCoef<float> {
+  static CURL_HD float seq(const float* c, int q) { return c[q]; }
+  static CURL_HD float ref(float x) { return x; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+struct PolyCoef<curl_f2> {
+  static CURL_HD curl_f2 seq(const float* c, int q) { return splat2(c[q]); }
+  static CURL_HD curl_f2 ref(float x) { return splat2(x); }
+};
+#endif
+#define CURL_POLY_SPLAT(c) (c)
+#define CURL_POLY_FMA(a, v, c) poly_fmav(a, v, c)
 #define CURL_POLY_FMAV(a, v, q) poly_fmav(a, v, q)
 #include "poly_horner.inc"
 #undef CURL_POLY_SPLAT
@@ -42,6 +50,7 @@ struct PolyEval;
 template <>
 struct PolyEval<5> {
   static constexpr int kCoeffs = 126;
+  static constexpr int kSeqStride = 128;  // floats per polynomial in the consumption-order (LDS) layout: 16-byte multiple
   template <class F, bool SEQ, int NP>
   static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][5], const float* c) { poly_d4_v5<F, SEQ, NP>(out, v, c); }
   static CURL_HD int order(int pos) { return kPolyOrder_d4_v5[pos]; }
@@ -52,6 +61,7 @@ struct PolyEval<5> {
 template <>
 struct PolyEval<4> {  // 3 colour channels + x/W: the per-row collapsed form of the 5-variable polynomial (below)
   static constexpr int kCoeffs = 70;
+  static constexpr int kSeqStride = 72;
   template <class F, bool SEQ, int NP>
   static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][4], const float* c) { poly_d4_v4<F, SEQ, NP>(out, v, c); }
   static CURL_HD int order(int pos) { return kPolyOrder_d4_v4[pos]; }
@@ -59,6 +69,7 @@ struct PolyEval<4> {  // 3 colour channels + x/W: the per-row collapsed form of 
 template <>
 struct PolyEval<3> {
   static constexpr int kCoeffs = 35;
+  static constexpr int kSeqStride = 36;
   template <class F, bool SEQ, int NP>
   static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][3], const float* c) { poly_d4_v3<F, SEQ, NP>(out, v, c); }
   static CURL_HD int order(int pos) { return kPolyOrder_d4_v3[pos]; }
@@ -71,7 +82,9 @@ struct PolyEval<3> {
 // reference's order (SEQ = false) or permuted into Horner consumption order (SEQ = true).  vars is plane-major.
 template <int V, int N, bool SEQ = false>
 CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float* coef) {
-  constexpr int NC = PolyEval<V>::kCoeffs;
+  // SEQ layout: every polynomial starts on a 16-byte boundary (kSeqStride), so the sequential reads merge into
+  // ds_read_b64 / b128 with 16-bit offsets instead of ds_read2_b32 pairs that need a fresh base register every 1 KB
+  constexpr int NC = SEQ ? PolyEval<V>::kSeqStride : PolyEval<V>::kCoeffs;
 #if defined(__HIP_DEVICE_COMPILE__)
   // One output polynomial at a time, all pixel pairs of the lane in lock step (poly_horner.inc): the pairs share
   // every coefficient read (one broadcast ds_read_b128 feeds 4 terms x N/2 packed FMAs) and are the ILP of the
@@ -142,7 +155,7 @@ CURL_HD void sigmoid_run(float (&x)[M]) {
 // (cat_coords, model.py:487-497; unused when V == 3).  coef: [3 spaces = R, L, H][3][NC] of this image.
 template <int V, int N, bool SEQ = false>
 CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], const float* coef, bool residual_only) {
-  constexpr int NC = PolyEval<V>::kCoeffs;
+  constexpr int NC = SEQ ? PolyEval<V>::kSeqStride : PolyEval<V>::kCoeffs;
   PxN<N> lab = p, hsv = p;
   rgb2lab_n<N>(lab);
   rgb2hsv_n<N>(hsv);
@@ -245,7 +258,7 @@ CURL_HD float collapse_coef(const float* c126, int pos, float y) {
 template <int V, int N, bool SEQ>
 CURL_HD void trispace_bwd_n(const PxN<N>& in, const float (&xw)[N], const float (&yh)[N], const float* coef,
                             const PxN<N>& gout, bool residual_only, float (&vars)[3][3][N], float (&gP)[3][3][N]) {
-  constexpr int NC = PolyEval<V>::kCoeffs;
+  constexpr int NC = SEQ ? PolyEval<V>::kSeqStride : PolyEval<V>::kCoeffs;
   PxN<N> sp[3] = {in, in, in};
   rgb2lab_n<N>(sp[1]);
   rgb2hsv_n<N>(sp[2]);

@@ -194,10 +194,11 @@ int twin_trispace_rows(const float* img, const float* coeffs, float* out, int B,
   for (int b = 0; b < B; ++b) {
     const float* c = coeffs + (size_t)b * 9 * 126;
     for (int r = 0; r < H; ++r) {
-      float row_coef[9 * 70];
+      constexpr int NS4 = PolyEval<4>::kSeqStride;
+      float row_coef[9 * NS4] = {};
       const float y = (float)r / (float)H;
       for (int q = 0; q < 9; ++q)
-        for (int pos = 0; pos < 70; ++pos) row_coef[q * 70 + pos] = collapse_coef(c + q * 126, pos, y);
+        for (int pos = 0; pos < 70; ++pos) row_coef[q * NS4 + pos] = collapse_coef(c + q * 126, pos, y);
       for (int col = 0; col < W; ++col) {
         size_t i = (size_t)r * W + col;
         PxN<1> p{{img[(b * 3 + 0) * HW + i]}, {img[(b * 3 + 1) * HW + i]}, {img[(b * 3 + 2) * HW + i]}};

@@ -71,12 +71,16 @@ def gen(degree, nvars):
     assert sorted(order) == list(range(len(table)))
     n_fma = sum(1 for l in lines if "CURL_POLY_FMA" in l)
     # lock-step form: every statement runs over the NP pixel groups of the lane (NP independent chains), and a
-    # scheduling fence every FENCE_EVERY statements bounds how far ahead coefficient reads can be hoisted
+    # scheduling fence bounds how far ahead coefficient reads can be hoisted.  Fences are placed where the number of
+    # coefficients consumed so far is a multiple of 4 (>= FENCE_EVERY since the last one): every fenced region then
+    # reads a 16-byte-aligned run of the consumption-order table, which the compiler merges into ds_read_b128.
     FENCE_EVERY = 12
     out_lines = []
     import re
-    n_stmt = 0
+    used = 0        # coefficients consumed so far (the q of CURL_POLY_C(q) is sequential by construction)
+    last_fence = 0
     for l in lines:
+        used += len(re.findall(r"CURL_POLY_C\(", l))
         m = re.match(r"  F (t\d+) = (.*);", l)
         if m:
             name, rhs = m.group(1), m.group(2)
@@ -88,20 +92,21 @@ def gen(degree, nvars):
             name, rhs = m.group(1), m.group(2)
             rhs_p = re.sub(r"\b(t\d+)\b", r"\1[p]", rhs).replace("v[", "v[p][")
             out_lines.append(f"  CURL_POLY_EACH {name}[p] = {rhs_p};")
-            n_stmt += 1
-            if n_stmt % FENCE_EVERY == 0:
-                out_lines.append("  CURL_FENCE();")
+        if used % 4 == 0 and used - last_fence >= FENCE_EVERY:
+            out_lines.append("  CURL_FENCE();")
+            last_fence = used
     body = "\n".join(out_lines)
     tab = ", ".join(str(i) for i in order)
     return table, f"""// degree {degree}, {nvars} variables: {len(table)} coefficients, {n_fma} FMAs per chain
 // position in the order the Horner scheme consumes them -> coefficient index of the reference (generate_powers)
 constexpr unsigned short kPolyOrder_d{degree}_v{nvars}[{len(table)}] = {{{tab}}};
 // NP chains (pixel groups of one lane) advance in lock step.
-// SEQ = true: c already holds the coefficients in consumption order (the LDS copy: sequential ds_read_b128);
+// SEQ = true: c holds the coefficients in consumption order (the LDS copy: sequential, 16-byte aligned runs between
+// fences -> ds_read_b128);
 // SEQ = false: c is the reference's layout, indexed through the (compile-time) table.
 template <class F, bool SEQ, int NP>
 CURL_HD void poly_d{degree}_v{nvars}(F (&out)[NP], const F (&v)[NP][{nvars}], const float* c) {{
-#define CURL_POLY_C(q) (SEQ ? c[q] : c[kPolyOrder_d{degree}_v{nvars}[q]])
+#define CURL_POLY_C(q) (SEQ ? PolyCoef<F>::seq(c, q) : PolyCoef<F>::ref(c[kPolyOrder_d{degree}_v{nvars}[q]]))
 #define CURL_POLY_EACH _Pragma("unroll") for (int p = 0; p < NP; ++p)
 {body}
   CURL_POLY_EACH out[p] = {result}[p];
@@ -155,7 +160,7 @@ def main():
     parts = ["// GENERATED by tools/gen_poly_horner.py -- do not edit.\n"
              "// Multivariate Horner evaluators in the coefficient order of the reference's generate_powers\n"
              "// (model.py:222-246).  F = float (host twin) or a packed 2-pixel vector (gfx950: v_pk_fma_f32).\n"
-             "// CURL_POLY_SPLAT(c): F from a scalar; CURL_POLY_FMA(a, v, c): a*v + splat(c); CURL_POLY_FMAV(a, v, q): a*v + q.\n"]
+             "// CURL_POLY_C(q): coefficient q as an F; CURL_POLY_SPLAT(c): identity; CURL_POLY_FMA / FMAV(a, v, q): a*v + q.\n"]
     for degree, nvars in ((4, 5), (4, 3), (4, 4)):
         table, code = gen(degree, nvars)
         parts.append(code)
