@@ -106,7 +106,10 @@ int curl_hsv2rgb_f32(const float* in, float* out, int B, int H, int W, unsigned 
 
 /* replaces: the first stage of CURLLayer.forward closed back to RGB, model.py:151-157
  *           (rgb2lab -> adjust_lab -> *mask -> lab2rgb) as ONE pass over the pixels.
- * rawL [B, 3*Kl]. reg [B] (nullable) is assigned reg_lab. */
+ * rawL [B, 3*Kl]. reg [B] (nullable) is assigned reg_lab.
+ * flags: CURL_F_PWL evaluates the three curves as the PAPER's clamped piecewise-linear interpolation of the knots
+ * (knots and slopes of the image staged in LDS, interval = direct index, two per-lane gathers + one fma per curve)
+ * instead of the reference's affine form -- a non-parity option, as for curl_adjust_*. */
 int curl_lab_stage_f32(const float* img, const void* mask, int mask_kind, const float* rawL,
                        float* out, float* reg, void* workspace, size_t workspace_bytes,
                        int B, int H, int W, int Kl, unsigned flags, curl_stream_t stream);

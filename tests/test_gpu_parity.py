@@ -721,3 +721,28 @@ def test_layer_randomised_stress_vs_oracle(ops, dev):
         assert float((out.double() - r64).abs().max()) <= 3.0 * noise + 5e-6, (case, B, H, W, kind, sigma)
         assert float((out - ref).abs().max()) <= 4.0 * noise + 5e-6, (case, B, H, W, kind, sigma)
         np.testing.assert_allclose(N(reg), rreg.numpy(), rtol=3e-6)
+
+
+@pytest.mark.parametrize("K,mask_kind", [(16, None), (16, "bool"), (5, "f32"), (40, "bool")])
+def test_lab_stage_pwl_fused_equals_the_separate_steps(ops, dev, K, mask_kind):
+    """CURL_F_PWL on the fused Lab stage (knots in LDS, direct interval index, lerp) == RGB->Lab, adjust_lab with the
+    same flag, x mask, Lab->RGB through the separate entry points; and it is NOT the affine form (the option is real)."""
+    from curl_amd import _lib
+    g = torch.Generator().manual_seed(K)
+    B, H, W = 2, 37, 52
+    img = (torch.rand(B, 3, H, W, generator=g) * 1.1 - 0.05).to(dev)
+    L = (torch.randn(B, 3 * K, generator=g) * 0.3).to(dev)
+    mask = None
+    if mask_kind == "bool":
+        mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+    elif mask_kind == "f32":
+        mask = torch.rand(B, 1, H, W, generator=g).to(dev)
+    fused, reg = ops.lab_stage(img, mask, L, flags=_lib.F_PWL)
+    lab, reg2 = ops.adjust_lab(ops.rgb2lab(img), L, flags=_lib.F_PWL)
+    if mask is not None:
+        lab = lab * mask
+    steps = ops.lab2rgb(lab.contiguous())
+    assert float((fused - steps).abs().max()) <= 2e-6
+    assert torch.equal(reg, reg2)
+    affine, _ = ops.lab_stage(img, mask, L)
+    assert float((fused - affine).abs().max()) > 1e-3
