@@ -598,6 +598,15 @@ CURL_HD float scale_pwl(float x, const float* C, const float* sl, int K) {
   return fmaf(sl[i], frac, C[i]);
 }
 
+// the same with knot and slope interleaved, {C_i, slope_i} at tab[2 i]: one 8-byte gather per lookup (fused kernels)
+CURL_HD float scale_pwl_pairs(float x, const float* tab, int K) {
+  float sx = (float)(K - 1) * x;
+  float fi = clampf(floorf(sx), 0.0f, (float)(K - 2));
+  int i = (int)fi;
+  float frac = clamp01(sx - fi);
+  return fmaf(tab[2 * i + 1], frac, tab[2 * i]);
+}
+
 struct LayerCoef {
   Affine lab[3], rgb[3], hsv[4];
 };

@@ -167,8 +167,8 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
       vars[0][i] = q.c0[i];
       vars[1][i] = q.c1[i];
       vars[2][i] = q.c2[i];
-      if (V >= 4) vars[3][i] = xw[i];
-      if (V == 5) vars[4][i] = yh[i];
+      if constexpr (V >= 4) vars[3][i] = xw[i];
+      if constexpr (V == 5) vars[4][i] = yh[i];
     }
   };
   auto squash = [&]() {  // sigmoid over the 3N outputs
@@ -271,8 +271,8 @@ CURL_HD void trispace_bwd_n(const PxN<N>& in, const float (&xw)[N], const float 
       vars[s][0][i] = v[0][i] = sp[s].c0[i];
       vars[s][1][i] = v[1][i] = sp[s].c1[i];
       vars[s][2][i] = v[2][i] = sp[s].c2[i];
-      if (V >= 4) v[3][i] = xw[i];
-      if (V == 5) v[4][i] = yh[i];
+      if constexpr (V >= 4) v[3][i] = xw[i];
+      if constexpr (V == 5) v[4][i] = yh[i];
     }
     poly3_n<V, N, SEQ>(o, v, coef + s * 3 * NC);
     float flat[3 * N];

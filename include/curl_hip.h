@@ -117,7 +117,9 @@ int curl_lab_stage_f32(const float* img, const void* mask, int mask_kind, const 
 /* replaces: CURLLayer.forward(img, mask, L, R, H)  model.py:137-176, as ONE pass over the pixels.
  * rawL [B,3*Kl], rawR [B,3*Kr], rawH [B,4*Kh] (the slices L[:, :48], R[:, :48], H[:, :64] of
  * model.py:153,159,165, made contiguous by the caller).  reg [B] (nullable) is assigned
- * reg_rgb + reg_lab + reg_hsv (model.py:172-174). */
+ * reg_rgb + reg_lab + reg_hsv (model.py:172-174).
+ * flags: CURL_F_PWL = all ten curves as the paper's clamped piecewise-linear interpolation, knots and slopes of the
+ * image staged in LDS (non-parity option, see curl_lab_stage_f32). */
 int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind,
                        const float* rawL, const float* rawR, const float* rawH,
                        float* out, float* reg, void* workspace, size_t workspace_bytes,

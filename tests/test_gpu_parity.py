@@ -746,3 +746,33 @@ def test_lab_stage_pwl_fused_equals_the_separate_steps(ops, dev, K, mask_kind):
     assert torch.equal(reg, reg2)
     affine, _ = ops.lab_stage(img, mask, L)
     assert float((fused - affine).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("Ks,mask_kind", [((16, 16, 16), None), ((16, 16, 16), "bool"), ((5, 9, 7), "f32")])
+def test_layer_pwl_fused_equals_the_separate_steps(ops, dev, Ks, mask_kind):
+    """CURL_F_PWL on the fused layer == the chain of model.py:150-170 run through the separate entry points with the
+    same flag on every adjust_* (ten curves from LDS, three different knot counts)."""
+    from curl_amd import _lib
+    Kl, Kr, Kh = Ks
+    g = torch.Generator().manual_seed(sum(Ks))
+    B, H, W = 2, 33, 44
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.3).to(dev) for n in (3 * Kl, 3 * Kr, 4 * Kh))
+    mask = None
+    if mask_kind == "bool":
+        mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+    elif mask_kind == "f32":
+        mask = torch.rand(B, 1, H, W, generator=g).to(dev)
+    m = 1.0 if mask is None else mask.float()
+    fused, reg = ops.curl_layer_forward(img, mask, L, R, Hk, flags=_lib.F_PWL)
+    x, r_lab = ops.adjust_lab(ops.rgb2lab(img), L, flags=_lib.F_PWL)
+    x = ops.lab2rgb((x * m).contiguous())
+    x, r_rgb = ops.adjust_rgb(x, R, flags=_lib.F_PWL)
+    x = ops.rgb2hsv((x * m).contiguous())
+    x, r_hsv = ops.adjust_hsv(x, Hk, flags=_lib.F_PWL)
+    res = ops.hsv2rgb((x * m).contiguous())
+    steps = (img + res).clamp(0, 1) * m
+    assert float((fused - steps).abs().max()) <= 3e-6
+    np.testing.assert_allclose(N(reg), N((r_rgb + r_lab) + r_hsv), rtol=1e-6)
+    affine, _ = ops.curl_layer_forward(img, mask, L, R, Hk)
+    assert float((fused - affine).abs().max()) > 1e-3
