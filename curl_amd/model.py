@@ -31,10 +31,13 @@ class _CurlLayerFn(torch.autograd.Function):
 
 
 class CURLLayer(nn.Module):
-    """model.py:121-176.  Same constructor arguments, same forward signature and returns."""
+    """model.py:121-176.  Same constructor arguments, same forward signature and returns.
+    `paper_pwl=True` (not in the reference) evaluates the curves as the paper's clamped piecewise-linear
+    interpolation of the knots (CURL_F_PWL: knots in LDS) instead of the reference's affine form; inference only."""
 
-    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64):
+    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64, paper_pwl=False):
         super().__init__()
+        self.paper_pwl = paper_pwl
         self.num_lab_points = num_lab_points
         self.num_rgb_points = num_rgb_points
         self.num_hsv_points = num_hsv_points
@@ -52,7 +55,12 @@ class CURLLayer(nn.Module):
         L = L[:, :self.num_lab_points]  # model.py:153
         R = R[:, :self.num_rgb_points]  # model.py:159
         H = H[:, :self.num_hsv_points]  # model.py:165
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (img, L, R, H)):
+        needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (img, L, R, H))
+        if self.paper_pwl:
+            if needs_grad:
+                raise NotImplementedError("curl_amd: paper_pwl has no backward (the reference's curves are the affine form)")
+            return ops.curl_layer_forward(img, mask, L, R, H, flags=ops.F_PWL)
+        if needs_grad:
             return _CurlLayerFn.apply(img, mask, L, R, H)
         return ops.curl_layer_forward(img, mask, L, R, H)
 
