@@ -3,12 +3,41 @@
 PyTorch is plumbing here: it owns device memory (caching allocator) and the stream.
 Every function enqueues on torch's CURRENT stream and returns without synchronising.
 """
+import functools
 from types import SimpleNamespace
 
 import torch
 
 from . import _lib
 from ._lib import F_EXACT_ORDER, F_PWL, MASK_F32, MASK_NONE, MASK_U8
+
+
+def _empty_ok(mask_arg=None):
+    """The reference's eager ops accept empty tensors ([0,3,H,W], or H*W == 0) and return empty ones; the kernels
+    are never launched on zero pixels.  Ops that also return a regulariser still owe it (it depends on the knots
+    only): it is produced by the same entry point on a 1x1 stand-in image."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(img, *args, **kwargs):
+            if not (isinstance(img, torch.Tensor) and img.dim() == 4 and img.shape[1] == 3 and img.numel() == 0):
+                return fn(img, *args, **kwargs)
+            _need_device(img, "img")
+            out = torch.empty_like(img)
+            if mask_arg is None:          # image -> image
+                return out
+            B = img.shape[0]
+            if B == 0:
+                reg = torch.zeros(0, dtype=torch.float32, device=img.device)
+            else:
+                args = list(args)
+                if mask_arg >= 0:
+                    args[mask_arg] = None  # the mask's shape belongs to the empty image
+                kwargs.pop("out", None)
+                res = fn(img.new_zeros((B, 3, 1, 1)), *args, **kwargs)
+                reg = res[1]
+            return out, reg
+        return wrapper
+    return deco
 
 
 def _stream(t):
@@ -80,6 +109,7 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------ curves.py
+@_empty_ok(mask_arg=-1)
 def apply_curve(img, C, slope_sqr_diff, channel_in, channel_out, flags=F_EXACT_ORDER):
     """curves.apply_curve (curves.py:4-38).  C are the knots after exp, [B,K].
     slope_sqr_diff [B] is updated in place (curves.py:24) and returned; None skips it."""
@@ -99,7 +129,7 @@ def apply_curve(img, C, slope_sqr_diff, channel_in, channel_out, flags=F_EXACT_O
     return out, reg
 
 
-def _adjust(fn_name, ncurves, img, raw, flags):
+def _adjust(fn_name, ncurves, img, raw, flags):  # noqa: E302
     lib = _lib.load()
     img = _image(img)
     B, _, H, W = img.shape
@@ -113,16 +143,19 @@ def _adjust(fn_name, ncurves, img, raw, flags):
     return out, reg
 
 
+@_empty_ok(mask_arg=-1)
 def adjust_rgb(img, R, flags=0):
     """curves.adjust_rgb (curves.py:90-133), regulariser seeded with zeros."""
     return _adjust("curl_adjust_rgb_f32", 3, img, R, flags)
 
 
+@_empty_ok(mask_arg=-1)
 def adjust_lab(img, L, flags=0):
     """curves.adjust_lab (curves.py:136-180)."""
     return _adjust("curl_adjust_lab_f32", 3, img, L, flags)
 
 
+@_empty_ok(mask_arg=-1)
 def adjust_hsv(img, S, flags=0):
     """curves.adjust_hsv (curves.py:41-87)."""
     return _adjust("curl_adjust_hsv_f32", 4, img, S, flags)
@@ -139,27 +172,32 @@ def _convert(fn_name, img, flags=0):
     return out
 
 
+@_empty_ok()
 def rgb2lab(img, flags=0):
     """colors.RGB2LAB.forward (colors.py:27-62)."""
     return _convert("curl_rgb2lab_f32", img, flags)
 
 
+@_empty_ok()
 def lab2rgb(img, flags=0):
     """colors.LAB2RGB.forward (colors.py:88-123)."""
     return _convert("curl_lab2rgb_f32", img, flags)
 
 
+@_empty_ok()
 def rgb2hsv(img, flags=0):
     """colors.RGB2HSV.forward (colors.py:195-242)."""
     return _convert("curl_rgb2hsv_f32", img, flags)
 
 
+@_empty_ok()
 def hsv2rgb(img, flags=0):
     """colors.HSV2RGB.forward (colors.py:131-177)."""
     return _convert("curl_hsv2rgb_f32", img, flags)
 
 
 # ------------------------------------------------------------------ model.py: fused stages
+@_empty_ok(mask_arg=0)
 def lab_stage(img, mask, L, flags=0, out=None):
     """RGB -> Lab -> 3 curves -> *mask -> RGB in one pass (model.py:151-157). -> (rgb, reg_lab)."""
     lib = _lib.load()
@@ -176,6 +214,7 @@ def lab_stage(img, mask, L, flags=0, out=None):
     return out, reg
 
 
+@_empty_ok(mask_arg=0)
 def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     """CURLLayer.forward (model.py:137-176) in one pass over the pixels. -> (img, reg[B]).
     L [B,3*Kl], R [B,3*Kr], H [B,4*Kh] are the already-sliced raw knots."""
@@ -229,6 +268,7 @@ def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_i
 
 
 # ------------------------------------------------------------------ polynomial path (model.py:206-520)
+@_empty_ok()
 def trispace_forward(img, coeffs, residual_only=False, flags=0):
     """TriSpaceRegNet.generate_residual (+ generate_image unless residual_only), model.py:499-520, in one pass.
     coeffs [B,3,3,NC] with NC = 126 (spatial) or 35; [:,0]=R, [:,1]=L, [:,2]=H (model.py:526)."""

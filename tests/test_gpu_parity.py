@@ -776,3 +776,25 @@ def test_layer_pwl_fused_equals_the_separate_steps(ops, dev, Ks, mask_kind):
     np.testing.assert_allclose(N(reg), N((r_rgb + r_lab) + r_hsv), rtol=1e-6)
     affine, _ = ops.curl_layer_forward(img, mask, L, R, Hk)
     assert float((fused - affine).abs().max()) > 1e-3
+
+
+def test_empty_inputs_behave_like_the_eager_reference(ops, dev):
+    """torch's eager ops take empty tensors in their stride: an empty batch or a zero-pixel image comes back empty,
+    and the regulariser (a function of the knots alone) is still returned."""
+    L, R, Hk = (torch.randn(2, n, device=dev) * 0.1 for n in (48, 48, 64))
+    for shape in ((0, 3, 8, 8), (2, 3, 0, 5)):
+        img = torch.empty(*shape, device=dev)
+        B = shape[0]
+        for conv in (ops.rgb2lab, ops.lab2rgb, ops.rgb2hsv, ops.hsv2rgb):
+            assert conv(img).shape == img.shape
+        out, reg = ops.curl_layer_forward(img, None, L[:B], R[:B], Hk[:B])
+        assert out.shape == img.shape and reg.shape == (B,)
+        out, reg_l = ops.lab_stage(img, torch.ones(B, 1, *shape[2:], dtype=torch.bool, device=dev), L[:B])
+        assert out.shape == img.shape and reg_l.shape == (B,)
+        out, reg_r = ops.adjust_rgb(img, R[:B])
+        assert out.shape == img.shape
+        if B:
+            full, reg_full = ops.adjust_rgb(torch.rand(B, 3, 4, 4, device=dev), R[:B])
+            assert torch.equal(reg_r, reg_full)  # the same number as with pixels
+        c = torch.zeros(B, 3, 3, 126, device=dev)
+        assert ops.trispace_forward(img, c).shape == img.shape
