@@ -29,7 +29,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
-from . import metric, model
+from . import evaluate, model
 
 
 class SyntheticPairs(Dataset):
@@ -73,28 +73,6 @@ def forward_image(net, img, mask):
     return out[0] if isinstance(out, tuple) else out  # the curve model also returns its regulariser
 
 
-@torch.no_grad()
-def evaluate(net, criterion, loader, device, world):
-    """evaluate.py:74-139 (Evaluator.evaluate) without the image dump: mean loss, mean masked PSNR (batches whose
-    PSNR is undefined are left out of its mean, evaluate.py:111-112) and mean MS-SSIM of the masked RGB images
-    (evaluate.py:103-104: MSSSIMMetric() defaults, 3 channels, window 11), summed over ranks like its gather."""
-    net.eval()
-    psnr, msssim = metric.PSNRMetric(), metric.MSSSIMMetric().to(device)
-    acc = torch.zeros(5, dtype=torch.float64, device=device)  # loss sum, batches, psnr sum, psnr batches, msssim sum
-    for batch in loader:
-        img, gt, mask = (batch[k].to(device, non_blocking=True) for k in ("input_img", "output_img", "mask"))
-        out = forward_image(net, img, mask)
-        p = psnr(gt, out, mask)
-        one = torch.ones((), dtype=torch.float64, device=device)
-        acc += torch.stack((criterion(out, gt, mask).double(), one,
-                            p.double() if p is not None else 0 * one, one if p is not None else 0 * one,
-                            msssim(gt * mask, out * mask).mean().double()))
-    if world > 1:
-        dist.all_reduce(acc)
-    net.train()
-    return float(acc[0] / acc[1]), float(acc[2] / acc[3].clamp(min=1)), float(acc[4] / acc[1])
-
-
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Train the enhancement model (shape of the reference's main.py)")
     ap.add_argument("--num_epoch", type=int, default=4)
@@ -112,6 +90,7 @@ def main(argv=None):
     ap.add_argument("--width", type=float, default=1.0, help="encoder width multiplier")
     ap.add_argument("--log_dirpath", type=str, default=None, help="where checkpoints go (rank 0); none = no files")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--save_images", action="store_true", help="dump validation outputs under --log_dirpath (evaluate.py:49-66)")
     ap.add_argument("--amp", choices=("off", "bf16"), default="off",
                     help="bf16: torch.autocast around the encoder (stock PyTorch-ROCm); the per-pixel HIP kernels and "
                          "the loss always run in float32 (their autograd nodes cast inputs back)")
@@ -151,6 +130,7 @@ def main(argv=None):
     if ddp:
         net = nn.parallel.DistributedDataParallel(net, device_ids=[device.index], output_device=device.index)  # main.py:225
     criterion = model.CURLLoss(ssim_window_size=5).to(device)                 # main.py:228
+    validation_evaluator = evaluate.Evaluator(criterion, valid_loader, "valid", args.log_dirpath, local_rank=rank)  # main.py:233
     optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, net.parameters()), lr=5e-7, betas=(0.5, 0.999))
     scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=1e-4, total_steps=args.num_epoch)
     start_epoch = 0
@@ -189,8 +169,8 @@ def main(argv=None):
                  "train_loss": sum(t[0] for t in totals) / max(1, sum(t[1] for t in totals))}
         scheduler.step()
         if (epoch + 1) % args.valid_every == 0:                               # main.py:313-340
-            entry["valid_loss"], entry["valid_psnr"], entry["valid_msssim"] = evaluate(net, criterion, valid_loader, device,
-                                                                                       world if ddp else 1)
+            entry["valid_loss"], entry["valid_psnr"], entry["valid_msssim"] = validation_evaluator.evaluate(
+                net, epoch, save_images=args.save_images and bool(args.log_dirpath))
             if rank == 0 and args.log_dirpath:
                 os.makedirs(args.log_dirpath, exist_ok=True)
                 path = os.path.join(args.log_dirpath, "curl_validpsnr_{}_validloss_{}_epoch_{}_model.pt".format(

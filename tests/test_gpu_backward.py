@@ -260,8 +260,15 @@ def test_train_driver_two_rank_ddp(dev, arch):
 
 def test_train_driver_checkpoint_resume(dev, tmp_path):
     """main.py:241-250 / 332-338: the checkpoint holds the reference's keys and a resumed run continues at its epoch."""
-    res = _run_train(SMALL + ["--num_epoch", "2", "--log_dirpath", str(tmp_path)])
+    res = _run_train(SMALL + ["--num_epoch", "2", "--log_dirpath", str(tmp_path), "--save_images"])
     ckpt = res["epochs"][0]["checkpoint"]
+    # the Evaluator's image dump (evaluate.py:49-66): <log>/valid/<epoch>/<name>, uint8 RGB files
+    from PIL import Image
+    dumped = sorted((tmp_path / "valid" / "1").glob("*.png"))
+    assert len(dumped) == 8
+    im = np.asarray(Image.open(dumped[0]))
+    assert im.shape == (64, 64, 3) and im.dtype == np.uint8
+    assert all(np.isfinite(res["epochs"][i]["valid_msssim"]) for i in range(2))
     state = torch.load(ckpt, map_location="cpu")
     assert set(state) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "loss"}
     assert state["epoch"] == 1
