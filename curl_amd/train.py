@@ -14,8 +14,9 @@ Encoder forward/backward is stock PyTorch-ROCm; every per-pixel piece (polynomia
 backward, the loss's colour terms, PSNR) is the HIP library.  Gradients of the per-image coefficients are local
 to the rank that owns the image; the only collective is DDP's bucketed all-reduce of the encoder's gradients.
 
-Data: the Adobe-5k-DPE folders are not available offline and data.py needs torchvision, so `--training_img_dirpath
-synthetic` (the default) draws seeded random crops whose ground truth is a fixed smooth retouch of the input.
+Data: `--training_img_dirpath <dir>` reads the reference's folder layout through curl_amd.data (data.py without
+torchvision); the Adobe-5k-DPE folders are not available offline, so the default `synthetic` draws seeded random crops
+whose ground truth is a fixed smooth retouch of the input.
 """
 import argparse
 import contextlib
@@ -29,7 +30,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
-from . import evaluate, model
+from . import data, evaluate, model
 
 
 class SyntheticPairs(Dataset):
@@ -101,9 +102,6 @@ def main(argv=None):
                     help="torch.backends.cudnn.benchmark: let MIOpen time its solvers per convolution shape")
     args = ap.parse_args(argv)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
-    if args.training_img_dirpath != "synthetic":
-        raise NotImplementedError("only --training_img_dirpath synthetic: the reference's data.py (torchvision, "
-                                  "Adobe-5k-DPE folders) is outside this path; plug any Dataset with its item keys")
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     ddp = args.parallel_mode == "ddp" and world > 1
     n_dev = torch.cuda.device_count()
@@ -114,8 +112,18 @@ def main(argv=None):
         dist.init_process_group(args.backend, **({"device_id": device} if args.backend == "nccl" else {}))
     torch.manual_seed(args.seed)  # same initial weights on every rank (DDP broadcasts rank 0's anyway)
 
-    train_set = SyntheticPairs(args.train_items, args.crop, seed=1)
-    valid_set = SyntheticPairs(args.valid_items, args.crop, seed=2)
+    if args.training_img_dirpath == "synthetic":
+        train_set = SyntheticPairs(args.train_items, args.crop, seed=1)
+        valid_set = SyntheticPairs(args.valid_items, args.crop, seed=2)
+    else:  # main.py:196-210: <dir>/{*input*,*output*,*mask*}/<id>.<ext> + images_train.txt / images_valid.txt
+        root = os.path.join(args.training_img_dirpath, "")
+        data_dict = data.get_data_dict(root)
+        train_ids = data.get_data_ids(os.path.join(root, "images_train.txt"))
+        valid_ids = data.get_data_ids(os.path.join(root, "images_valid.txt"))
+        train_set = data.Dataset(data.filter_data_dict(data_dict, train_ids), normaliser=1, is_train=True,
+                                 crop_h=args.crop, crop_w=args.crop, seed=args.seed * 7919 + rank)
+        valid_set = data.Dataset(data.filter_data_dict(data_dict, valid_ids), normaliser=1, is_train=False,
+                                 crop_h=args.crop, crop_w=args.crop)
     train_sampler = DistributedSampler(train_set) if ddp else None           # main.py:213
     valid_sampler = DistributedSampler(valid_set, shuffle=False) if ddp else None
     train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=(train_sampler is None), pin_memory=True,

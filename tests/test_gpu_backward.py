@@ -374,3 +374,28 @@ def test_msssim_hip_odd_shapes_vs_torch_route(dev, shape):
     ref.sum().backward()
     assert float((out - ref).abs().max()) <= 3e-6
     assert float((a1.grad - a2.grad).abs().max()) <= 1e-3 * float(a2.grad.abs().max())
+
+
+def test_train_driver_reads_the_reference_folder_layout(dev, tmp_path):
+    """--training_img_dirpath <dir>: main.py:196-210's layout (input / output / mask folders, images_train.txt,
+    images_valid.txt) through curl_amd.data, one epoch with validation."""
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for d in ("curl_example_input", "curl_example_output", "masks"):
+        os.makedirs(tmp_path / d)
+    for i in range(12):
+        h, w = int(rng.integers(70, 100)), int(rng.integers(70, 100))
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(rgb).save(tmp_path / "curl_example_input" / f"{i}.png")
+        Image.fromarray((rgb.astype(np.float32) ** 0.9).clip(0, 255).astype(np.uint8)).save(tmp_path / "curl_example_output" / f"{i}.png")
+        m = np.full((h, w), 255, np.uint8)
+        m[: h // 5] = 0
+        Image.fromarray(m).save(tmp_path / "masks" / f"{i}.png")
+    (tmp_path / "images_train.txt").write_text("\n".join(str(i) for i in range(8)) + "\n")
+    (tmp_path / "images_valid.txt").write_text("\n".join(str(i) for i in range(8, 12)) + "\n")
+    res = _run_train(["--training_img_dirpath", str(tmp_path), "--crop", "64", "--batch_size", "4", "--width", "0.25",
+                      "--num_epoch", "1", "--valid_every", "1"])
+    e = res["epochs"][0]
+    assert np.isfinite(e["train_loss"]) and np.isfinite(e["valid_loss"]) and np.isfinite(e["valid_psnr"])
+    assert 0.0 < e["valid_msssim"] <= 1.0

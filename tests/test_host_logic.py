@@ -152,3 +152,51 @@ def test_reference_style_checkpoint_loads_into_curllayer():
     layer2.load_state_dict(convert_state_dict(sd))
     for k, v in layer.state_dict().items():
         assert torch.equal(v, layer2.state_dict()[k])
+
+
+def test_folder_dataset_mirror(tmp_path):
+    """curl_amd.data: the reference's folder layout (data.py:43-80), one transform for input / output / mask, item keys
+    and dtypes of data.py:176-207, centre crop in evaluation mode, zero padding of too-small images."""
+    import importlib.util
+    import os
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("curl_amd_data_only", os.path.join(root, "curl_amd", "data.py"))
+    data = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(data)
+    rng = np.random.default_rng(0)
+    for d in ("curl_input", "curl_output", "masks"):
+        os.makedirs(tmp_path / d)
+    for i, (h, w) in enumerate([(80, 96), (40, 50), (300, 280)]):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(rgb).save(tmp_path / "curl_input" / f"{i}.png")
+        Image.fromarray(rgb).save(tmp_path / "curl_output" / f"{i}.png")          # output == input: must stay equal
+        m = np.zeros((h, w), np.uint8)
+        m[h // 4:, w // 3:] = 255
+        Image.fromarray(m, "L").save(tmp_path / "masks" / f"{i}.png")
+    (tmp_path / "images_train.txt").write_text("0\n2\n")
+    dd = data.get_data_dict(os.path.join(str(tmp_path), ""))
+    assert sorted(dd) == [0, 1, 2] and dd[1]["mask"].endswith("masks/1.png")
+    ids = data.get_data_ids(str(tmp_path / "images_train.txt"))
+    assert ids == [0, 2]
+    sub = data.filter_data_dict(dd, ids)
+    assert sorted(sub) == [0, 1] and sub[1] is dd[2]
+    train = data.Dataset(sub, normaliser=1, is_train=True, crop_h=64, crop_w=64, seed=3)
+    for k in range(4):
+        item = train[k % 2]
+        assert item["input_img"].shape == (3, 64, 64) and item["input_img"].dtype == torch.float32
+        assert item["mask"].shape == (1, 64, 64) and item["mask"].dtype == torch.bool
+        assert torch.equal(item["input_img"], item["output_img"])                    # same crop / flips / rotation
+        assert 0.0 <= float(item["input_img"].min()) and float(item["input_img"].max()) <= 1.0
+        assert item["name"] in ("0.png", "2.png")
+    ev = data.Dataset(dd, normaliser=1, is_train=False, crop_h=64, crop_w=64)
+    a, b = ev[0], ev[0]
+    assert torch.equal(a["input_img"], b["input_img"])                               # deterministic centre crop
+    full = torch.from_numpy(np.asarray(Image.open(tmp_path / "curl_input" / "0.png"))).permute(2, 0, 1).float() / 255
+    assert torch.equal(a["input_img"], full[:, 8:72, 16:80])
+    small = ev[1]                                                                    # 40x50 image: zero padded
+    assert small["input_img"].shape == (3, 64, 64) and float(small["input_img"][:, 0, 0].abs().max()) == 0.0
+    # the rotation kernel: +-90 degrees on a square is an exact quarter turn
+    x = torch.arange(3 * 8 * 8, dtype=torch.float32).reshape(3, 8, 8)
+    r = data._rotate_nearest(x, 90.0)
+    assert torch.equal(r, torch.rot90(x, 1, (1, 2))) or torch.equal(r, torch.rot90(x, -1, (1, 2)))
