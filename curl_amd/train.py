@@ -80,6 +80,9 @@ def main(argv=None):
     ap.add_argument("--valid_every", type=int, default=2)
     ap.add_argument("--checkpoint_filepath", type=str, default=None)
     ap.add_argument("--training_img_dirpath", type=str, default="synthetic")
+    ap.add_argument("--inference_img_dirpath", type=str, default=None,
+                    help="with --checkpoint_filepath: evaluate that checkpoint on <dir> (images_inference.txt) and dump "
+                         "the outputs, main.py:147-193; no training")
     ap.add_argument("--batch_size", type=int, default=32, help="per process, as main.py:117 after its division")
     ap.add_argument("--num_workers", type=int, default=0)
     ap.add_argument("--parallel_mode", type=str, default=None, choices=["ddp"])
@@ -111,6 +114,26 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, **({"device_id": device} if args.backend == "nccl" else {}))
     torch.manual_seed(args.seed)  # same initial weights on every rank (DDP broadcasts rank 0's anyway)
+
+    if args.checkpoint_filepath and args.inference_img_dirpath:            # main.py:147-193
+        if args.parallel_mode is not None:
+            raise ValueError("Inference not supported with DP or DDP. Do not pass --parallel_mode parameter.")
+        from .convert_state import convert_state_dict
+        root = os.path.join(args.inference_img_dirpath, "")
+        dd = data.filter_data_dict(data.get_data_dict(root), data.get_data_ids(os.path.join(root, "images_inference.txt")))
+        loader = DataLoader(data.Dataset(dd, normaliser=1, is_train=False, crop_h=args.crop, crop_w=args.crop),
+                            batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+        net = build_net(args.arch, args.width, sync_bn=False)
+        ckpt = torch.load(args.checkpoint_filepath, map_location="cpu")
+        net.load_state_dict(convert_state_dict(ckpt["model_state_dict"]))  # DP/DDP "module." prefixes removed
+        net = net.to(device).eval()
+        log_dir = args.log_dirpath or "."
+        os.makedirs(log_dir, exist_ok=True)
+        ev = evaluate.Evaluator(model.CURLLoss().to(device), loader, "test", log_dir, local_rank=rank)
+        loss, psnr, msssim = ev.evaluate(net, epoch=0, save_images=True)
+        print(json.dumps({"mode": "inference", "arch": args.arch, "images": len(dd), "test_loss": loss, "test_psnr": psnr,
+                          "test_msssim": msssim, "images_dir": os.path.join(log_dir, "test", "1")}))
+        return
 
     if args.training_img_dirpath == "synthetic":
         train_set = SyntheticPairs(args.train_items, args.crop, seed=1)

@@ -399,3 +399,11 @@ def test_train_driver_reads_the_reference_folder_layout(dev, tmp_path):
     e = res["epochs"][0]
     assert np.isfinite(e["train_loss"]) and np.isfinite(e["valid_loss"]) and np.isfinite(e["valid_psnr"])
     assert 0.0 < e["valid_msssim"] <= 1.0
+    # main.py:147-193: the same driver evaluates a checkpoint on a folder (images_inference.txt) and dumps the outputs
+    res = _run_train(["--training_img_dirpath", str(tmp_path), "--crop", "64", "--batch_size", "4", "--width", "0.25",
+                      "--num_epoch", "1", "--valid_every", "1", "--log_dirpath", str(tmp_path / "log")])
+    (tmp_path / "images_inference.txt").write_text("9\n10\n11\n")
+    inf = _run_train(["--checkpoint_filepath", res["epochs"][0]["checkpoint"], "--inference_img_dirpath", str(tmp_path),
+                      "--crop", "64", "--batch_size", "2", "--width", "0.25", "--log_dirpath", str(tmp_path / "inf")])
+    assert inf["mode"] == "inference" and inf["images"] == 3 and np.isfinite(inf["test_psnr"])
+    assert sorted(p.name for p in (tmp_path / "inf" / "test" / "1").glob("*.png")) == ["10.png", "11.png", "9.png"]
