@@ -192,7 +192,7 @@ def test_folder_dataset_mirror(tmp_path):
     ev = data.Dataset(dd, normaliser=1, is_train=False, crop_h=64, crop_w=64)
     a, b = ev[0], ev[0]
     assert torch.equal(a["input_img"], b["input_img"])                               # deterministic centre crop
-    full = torch.from_numpy(np.asarray(Image.open(tmp_path / "curl_input" / "0.png"))).permute(2, 0, 1).float() / 255
+    full = torch.from_numpy(np.array(Image.open(tmp_path / "curl_input" / "0.png"))).permute(2, 0, 1).float() / 255
     assert torch.equal(a["input_img"], full[:, 8:72, 16:80])
     small = ev[1]                                                                    # 40x50 image: zero padded
     assert small["input_img"].shape == (3, 64, 64) and float(small["input_img"][:, 0, 0].abs().max()) == 0.0
