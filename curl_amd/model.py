@@ -253,6 +253,28 @@ class Deg4MobilePolyLayer(nn.Module):
         return ops.poly_layer(img, coeffs.reshape(img.shape[0], 3, self.num_coeffs))
 
 
+class PolyRegNet(nn.Module):
+    """model.py:418-436: encoder -> [B,3,35] coefficients -> sigmoid(ChannelPolyLayer(degree 4, 3 variables)(img)) * mask.
+    The polynomial layer is the HIP kernel (ops.poly_layer; forward only, like the reference's use of this class in
+    inference); the backbone is injectable as in TriSpaceRegNet (the reference downloads timm's efficientnetv2_rw_s)."""
+
+    def __init__(self, num_channels=3, polynomial_order=4, backbone=None, feature_width=1792):
+        super().__init__()
+        self.num_channels = num_channels
+        self.order = polynomial_order
+        self.polylayer = ChannelPolyLayer(degree=self.order, num_variables=self.num_channels)
+        self.num_coeffs = self.polylayer.num_coeffs
+        if backbone is None:
+            backbone = CurveEncoder(num_outputs=1, num_features=feature_width)
+        backbone.classifier = nn.Linear(in_features=feature_width, out_features=self.num_channels * self.num_coeffs)
+        self.backbone = backbone
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, img, mask):
+        coeffs = self.backbone(img).reshape(img.shape[0], self.num_channels, self.num_coeffs)
+        return self.sigmoid(self.polylayer(img, coeffs.detach() if not coeffs.requires_grad else coeffs)) * mask
+
+
 class TriSpaceRegNet(nn.Module):
     """model.py:439-535: encoder -> [B,3,3,num_coeffs] -> per-pixel degree-4 polynomials in RGB, Lab and HSV.
     generate_residual + generate_image run as one fused kernel (ops.trispace_forward).

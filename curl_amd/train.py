@@ -86,6 +86,8 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=32, help="per process, as main.py:117 after its division")
     ap.add_argument("--num_workers", type=int, default=0)
     ap.add_argument("--parallel_mode", type=str, default=None, choices=["ddp"])
+    ap.add_argument("--local_rank", type=int, default=0, help="accepted for torch.distributed.launch (main.py:91); "
+                                                              "the LOCAL_RANK environment variable wins")
     ap.add_argument("--arch", choices=("trispace", "curl"), default="trispace")
     ap.add_argument("--backend", default="nccl", help="nccl = RCCL over xGMI; gloo for rehearsals")
     ap.add_argument("--crop", type=int, default=256, help="data.py:86 crops 256x256 .. 'resize to 320' variants")

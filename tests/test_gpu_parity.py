@@ -798,3 +798,18 @@ def test_empty_inputs_behave_like_the_eager_reference(ops, dev):
             assert torch.equal(reg_r, reg_full)  # the same number as with pixels
         c = torch.zeros(B, 3, 3, 126, device=dev)
         assert ops.trispace_forward(img, c).shape == img.shape
+
+
+def test_polyregnet_module(dev):
+    """model.py:418-436: sigmoid(degree-4 polynomial in the 3 colour channels) * mask, against the oracle's layer."""
+    import curl_oracle as O
+    from curl_amd import model
+    torch.manual_seed(4)
+    net = model.PolyRegNet(backbone=model.CurveEncoder(1, width=0.25, num_features=128), feature_width=128).to(dev).eval()
+    img = torch.rand(2, 3, 40, 56, device=dev)
+    mask = (torch.rand(2, 1, 40, 56, device=dev) > 0.2).float()
+    with torch.no_grad():
+        out = net(img, mask)
+        coeffs = net.backbone(img).reshape(2, 3, 35)
+    ref = torch.sigmoid(O.channel_poly_layer(img.cpu(), coeffs.cpu(), degree=4)) * mask.cpu()
+    assert max_err(N(out), ref.numpy()) <= 1e-5
