@@ -272,7 +272,10 @@ class PolyRegNet(nn.Module):
 
     def forward(self, img, mask):
         coeffs = self.backbone(img).reshape(img.shape[0], self.num_channels, self.num_coeffs)
-        return self.sigmoid(self.polylayer(img, coeffs.detach() if not coeffs.requires_grad else coeffs)) * mask
+        if torch.is_grad_enabled() and coeffs.requires_grad:
+            raise NotImplementedError("curl_amd: PolyRegNet is forward-only (the trainable polynomial model of this "
+                                      "path is TriSpaceRegNet); wrap the call in torch.no_grad()")
+        return self.sigmoid(self.polylayer(img, coeffs)) * mask
 
 
 class TriSpaceRegNet(nn.Module):
