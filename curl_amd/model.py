@@ -212,6 +212,13 @@ class _TriSpaceFn(torch.autograd.Function):
         return None, ops.trispace_backward(img, coeffs, grad_out.contiguous(), ctx.residual_only), None
 
 
+def _no_grad_path(coeffs, who):
+    """The stand-alone polynomial layers are forward-only kernels; gradients flow through TriSpaceRegNet's fused path."""
+    if torch.is_grad_enabled() and coeffs.requires_grad:
+        raise NotImplementedError(f"curl_amd: {who} alone is forward-only; TriSpaceRegNet.forward / generate_residual "
+                                  "carry the backward (ops.trispace_backward). Use torch.no_grad() here.")
+
+
 class ChannelPolyLayer(nn.Module):
     """model.py:206-333.  forward(img [B,V,H,W], coeffs [B,num_out,num_coeffs]) -> [B,num_out,H,W].
     The HIP kernel covers what the fork uses: degree 4, V = 5 or 3, num_out = 3."""
@@ -238,6 +245,7 @@ class ChannelPolyLayer(nn.Module):
         if self.degree != 4 or self.num_variables not in (3, 5) or self.num_out != 3:
             raise NotImplementedError("the HIP polynomial kernel is built for degree 4, 3 or 5 variables, 3 outputs "
                                       "(the configurations model.py:426,450 use)")
+        _no_grad_path(coeffs, "ChannelPolyLayer")
         return ops.poly_layer(img, coeffs)
 
 
@@ -250,6 +258,7 @@ class Deg4MobilePolyLayer(nn.Module):
         self.powers = nn.Parameter(torch.Tensor(_powers(4, 5)), requires_grad=False)
 
     def forward(self, img, coeffs):
+        _no_grad_path(coeffs, "Deg4MobilePolyLayer")
         return ops.poly_layer(img, coeffs.reshape(img.shape[0], 3, self.num_coeffs))
 
 
