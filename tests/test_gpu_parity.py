@@ -813,3 +813,32 @@ def test_polyregnet_module(dev):
         coeffs = net.backbone(img).reshape(2, 3, 35)
     ref = torch.sigmoid(O.channel_poly_layer(img.cpu(), coeffs.cpu(), degree=4)) * mask.cpu()
     assert max_err(N(out), ref.numpy()) <= 1e-5
+
+
+def test_new_entry_points_reject_bad_arguments(ops, dev):
+    """Argument errors of the later entry points surface as ValueError before any launch."""
+    from curl_amd import _lib
+    a = torch.rand(1, 1, 64, 64, device=dev)
+    with pytest.raises(ValueError):
+        ops.msssim_stats(a, a, window_size=13)          # window > 11
+    with pytest.raises(ValueError):
+        ops.msssim_stats(a, a, window_size=4)           # even window
+    with pytest.raises(ValueError):
+        ops.msssim_stats(a[:, :, :20, :20].contiguous(), a[:, :, :20, :20].contiguous())  # < 32 px: five levels impossible
+    with pytest.raises(RuntimeError):
+        ops.msssim_stats(a, a[:, :, :32].contiguous())  # shape mismatch, like metric.py:181-183
+    img = torch.rand(1, 3, 8, 8, device=dev)
+    c = torch.zeros(1, 3, 3, 126, device=dev)
+    with pytest.raises(ValueError):
+        ops.trispace_backward(img, c[:, :, :, :100].contiguous(), img)    # neither 126 nor 35 coefficients
+    u8 = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=dev)
+    L, R, H = (torch.zeros(1, n, device=dev) for n in (48, 48, 64))
+    lib = _lib.load()
+    ws, nbytes = ops._workspace(1, 160, dev)
+    out, reg = torch.empty_like(u8), torch.empty(1, device=dev)
+    rc = lib.curl_layer_fwd_u8hwc(u8.data_ptr(), 0, 0, L.data_ptr(), R.data_ptr(), H.data_ptr(), 0, out.data_ptr(),
+                                  reg.data_ptr(), ws.data_ptr(), nbytes, 1, 8, 8, 16, 16, 16, _lib.F_PWL, ops._stream(u8))
+    assert rc < 0 and b"flag" in lib.curl_last_error()   # the byte entry points take no flags
+    # and the fused PWL forms need every curve to fit the LDS table
+    with pytest.raises(ValueError):
+        ops.lab_stage(img, None, torch.zeros(1, 3 * 300, device=dev), flags=_lib.F_PWL)
