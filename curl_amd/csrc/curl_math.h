@@ -167,7 +167,7 @@ struct Px {
 // ~5.8 ns per SIMD, the same instruction in a run of its own kind ~4.3 ns (alone 3.5).  The converters are
 // therefore written over the N pixels a lane owns, as phases: every phase of transcendentals is a run of
 // 3N (or N) back-to-back v_log / v_exp / v_rcp, fenced so the scheduler cannot interleave it again.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CURL_NO_FENCE)  // CURL_NO_FENCE: experiment build (tools/variants.py)
 #define CURL_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define CURL_FENCE() ((void)0)
