@@ -2,8 +2,12 @@
 """bench.py -- BASELINE.json's metric on the MI355X: Mpix/s through the fused curve-apply at
 1500x1000, batch 32 per GPU, plus PSNR delta vs the reference arithmetic (the oracle).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1 runs directly;
-    N>1 is launched by the driver through torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N=1 runs in this process.  N>1 under torch.distributed.run (RANK/WORLD_SIZE set: how the driver starts it) is one
+rank per GPU; N>1 started plainly launches `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+ITSELF as a child process -- before anything touches the GPU -- relays its output and exits with its code
+(the launcher shape of main.py:98-124: one process per GPU, init_process_group("nccl")).
 
 A step = one pass of the hot path over one batch: CURLLayer.forward (model.py:137-176) as the fused
 HIP kernel (RGB->Lab->curves->RGB->curves->HSV->curves->RGB + residual), inputs resident in HBM.
@@ -48,26 +52,34 @@ def make_inputs(B, device, seed, n_sets=2):
     return sets
 
 
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
 WORKLOADS = {
-    # name: (description, algorithmic bytes per pixel [SURVEY.md 8(d)], kernel name fragment, mask)
-    "layer": ("CURLLayer.forward fused 3-stage (RGB->Lab->RGB->HSV->RGB + residual), bool mask all ones "
-              "(every pixel computed)", 25.0, "OpLayer", "ones"),
-    "layer_disk": ("same kernel, bool disk mask ~70 % coverage (fully masked wavefronts take the constant "
-                   "shortcut)", 25.0, "OpLayer", "disk"),
-    "lab_stage": ("fused RGB->Lab->3 curves->mask->RGB (the kernel BASELINE's 70 % target names), bool mask all "
-                  "ones", 25.0, "OpLabStage", "ones"),
-    "rgb_only": ("RGB-only 3 curves (adjust_rgb, BASELINE configs[1]), no mask", 24.0, "OpAdjust3", None),
-    "trispace": ("TriSpaceRegNet per-pixel path (SURVEY 8f-1): 3 x degree-4 polynomial layers (126 coeffs x 3 outputs) in "
-                 "RGB/Lab/HSV + converters + clamp, fused; arithmetic-bound (~2.6 kFLOP/px)", 24.0, "OpTriSpace", None),
-    "layer_u8": ("CURLLayer.forward on interleaved uint8 HWC in and out (SURVEY 8f-2: byte/255 and truncating *255 "
-                 "fused), bool mask all ones", 7.0, "OpLayer", "ones"),
-    "trispace_u8": ("TriSpaceRegNet per-pixel path on interleaved uint8 HWC in and out (infer.py:35-47 fused)", 6.0,
-                    "OpTriSpace", None),
+    # name: description, algorithmic bytes per pixel [SURVEY.md 8(d)], kernel name fragment, mask, what bounds it
+    # ("hbm": the streaming kernels; "valu": the kernels DESIGN.md 3/3a show to be arithmetic-bound), and for the
+    # latter FLOP per pixel counted from the kernel's hot block (tools/flops_from_isa.py: v_pk_fma 4 per lane,
+    # v_fma 2, v_pk_mul/add 2, v_mul/add/sub/min/max 1, transcendental 1; integer / bit / move instructions 0).
+    "layer": dict(desc="CURLLayer.forward fused 3-stage (RGB->Lab->RGB->HSV->RGB + residual), bool mask all ones "
+                       "(every pixel computed)", bpp=25.0, frag="OpLayer", mask="ones", bound="hbm", flop_px=213.0),
+    "layer_disk": dict(desc="same kernel, bool disk mask ~70 % coverage (fully masked wavefronts take the constant "
+                            "shortcut)", bpp=25.0, frag="OpLayer", mask="disk", bound="hbm", flop_px=213.0),
+    "lab_stage": dict(desc="fused RGB->Lab->3 curves->mask->RGB (the kernel BASELINE's 70 % target names), bool mask "
+                           "all ones", bpp=25.0, frag="OpLabStage", mask="ones", bound="hbm", flop_px=136.0),
+    "rgb_only": dict(desc="RGB-only 3 curves (adjust_rgb, BASELINE configs[1]), no mask", bpp=24.0, frag="OpAdjust3",
+                     mask=None, bound="hbm", flop_px=9.0),
+    "trispace": dict(desc="TriSpaceRegNet per-pixel path (SURVEY 8f-1): 3 x degree-4 polynomial layers (126 coeffs x 3 "
+                          "outputs) in RGB/Lab/HSV + converters + clamp, fused", bpp=24.0, frag="OpTriSpace", mask=None,
+                     bound="valu", flop_px=1480.0),
+    "layer_u8": dict(desc="CURLLayer.forward on interleaved uint8 HWC in and out (SURVEY 8f-2: byte/255 and truncating "
+                          "*255 fused), bool mask all ones", bpp=7.0, frag="OpLayer", mask="ones", bound="valu",
+                     flop_px=225.0),
+    "trispace_u8": dict(desc="TriSpaceRegNet per-pixel path on interleaved uint8 HWC in and out (infer.py:35-47 fused)",
+                        bpp=6.0, frag="OpTriSpace", mask=None, bound="valu", flop_px=1495.0),
 }
 
 
 def make_step(name, ops, masks):
-    mask = masks.get(WORKLOADS[name][3])
+    mask = masks.get(WORKLOADS[name]["mask"])
     if name in ("layer", "layer_disk"):
         return lambda s: ops.curl_layer_forward(s[0], mask, s[1], s[2], s[3])
     if name == "lab_stage":
@@ -110,12 +122,27 @@ def timed_run(step, sets, steps, warmup, dist, device):
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / steps
+    dev_min = dev_ms
     if dist is not None:
         on = device if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=on)
+        t = torch.tensor([wall, dev_ms, -dev_ms], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
-    return wall, dev_ms
+        wall, dev_ms, dev_min = float(t[0]), float(t[1]), -float(t[2])
+    return wall, dev_ms, dev_min
+
+
+def cold_first_launch_us(step, sets, device):
+    """What a caller issuing ONE batch after an idle gap sees: the chip idles for half a second, then one step is
+    timed with events on the launch stream (the steady-state figures come after CLOCK_SETTLE_LAUNCHES launches)."""
+    step(sets[0])  # code object loaded, workspace allocated
+    torch.cuda.synchronize(device)
+    time.sleep(0.5)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    step(sets[1 % len(sets)])
+    ev1.record()
+    torch.cuda.synchronize(device)
+    return ev0.elapsed_time(ev1) * 1e3
 
 
 def accuracy_vs_oracle(ops, device):
@@ -176,19 +203,36 @@ def cpu_baseline():
 
 
 def load_traffic(kernel_fragment):
-    """HBM bytes per launch from the committed PMC pass (profiles/traffic_r*.json), or None."""
+    """HBM bytes per launch from the builder's committed PMC pass (profiles/traffic_r*.json: FETCH_SIZE doubled per the
+    gfx950 note + WRITE_SIZE, separate --pmc runs) and where it came from -- replayed, not observed in this run."""
     prof = os.path.join(ROOT, "profiles")
     if not os.path.isdir(prof):
-        return None
+        return None, None
     for f in sorted(os.listdir(prof), reverse=True):
         if f.startswith("traffic_") and f.endswith(".json"):
             try:
                 d = json.load(open(os.path.join(prof, f)))
                 if kernel_fragment in d:
-                    return d[kernel_fragment]["hbm_bytes_per_launch"]
+                    return d[kernel_fragment]["hbm_bytes_per_launch"], f"profiles/{f} (builder's rocprofv3 --pmc pass, not this run)"
             except Exception:
                 pass
-    return None
+    return None, None
+
+
+def self_launch(args):
+    """`bench.py --gpus N` started without a launcher: start N ranks as a CHILD process (never exec: this process
+    may not be replaced once a GPU is initialised, and nothing here has touched one yet) and relay its result."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -201,26 +245,33 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / cpu_baseline / accuracy")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: this path has no CPU fallback")
-    # one rank per GPU; (a rehearsal with more ranks than GPUs -- CURL_DIST_BACKEND=gloo on a 1-GPU box -- wraps)
-    device = torch.device("cuda", local % torch.cuda.device_count())
+    # one rank per GPU.  With fewer GPUs than ranks (a rehearsal on a 1-GPU box) ranks wrap onto the GPUs there are
+    # and the control plane falls back to gloo (RCCL cannot place two ranks on one device); the line says so.
+    n_dev = torch.cuda.device_count()
+    device = torch.device("cuda", local % n_dev)
     torch.cuda.set_device(device)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CURL_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("CURL_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist_mod.init_process_group(backend="nccl", device_id=device)
         else:
             dist_mod.init_process_group(backend=backend)
         dist = dist_mod
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: start it plainly (it launches its own ranks) "
+                 f"or with --nproc-per-node {args.gpus}")
 
     from curl_amd import _lib, ops
     _lib.load()  # fail loudly without the HIP library
@@ -231,22 +282,31 @@ def main():
              "ones": torch.ones(B, 1, H_IMG, W_IMG, dtype=torch.bool, device=device), None: None}
     npx_rank = B * H_IMG * W_IMG
 
-    def measure(name, steps, warmup):
-        desc, bpp, frag, _ = WORKLOADS[name]
+    def measure(name, steps, warmup, cold=False):
+        w = WORKLOADS[name]
+        bpp = w["bpp"]
         step = make_step(name, ops, masks)
-        wall, dev_ms = timed_run(step, sets, steps, warmup, dist, device)
+        cold_us = cold_first_launch_us(step, sets, device) if cold else None
+        wall, dev_ms, dev_ms_min = timed_run(step, sets, steps, warmup, dist, device)
         mpix = world * npx_rank * steps / wall / 1e6
-        achieved = npx_rank * bpp / (dev_ms * 1e-3) / 1e9
-        return {
-            "workload": desc, "value": mpix, "ms_per_step": wall / steps * 1e3, "device_ms_per_step": dev_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": load_traffic(frag) if B == 32 else None,  # PMC pass was taken at bs32
-                         "algorithmic_bytes_per_px": bpp, "px_per_launch": npx_rank,
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
-        }
+        gbps = npx_rank * bpp / (dev_ms * 1e-3) / 1e9
+        tflops = npx_rank * w["flop_px"] / (dev_ms * 1e-3) / 1e12
+        traffic, traffic_src = load_traffic(w["frag"]) if B == 32 else (None, None)  # PMC pass was taken at bs32
+        hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+               "frac_of_measured_copy_ceiling_6290": gbps / 6290.0}
+        valu = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,
+                "flop_per_px": w["flop_px"]}
+        roof = dict(hbm if w["bound"] == "hbm" else valu)
+        roof.update({"bound": w["bound"], "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_px": bpp, "px_per_launch": npx_rank,
+                     "secondary": {"bound": "valu", **valu} if w["bound"] == "hbm" else {"bound": "hbm", **hbm}})
+        res = {"workload": w["desc"], "value": mpix, "ms_per_step": wall / steps * 1e3, "device_ms_per_step": dev_ms,
+               "device_ms_per_step_min_over_ranks": dev_ms_min, "roofline": roof}
+        if cold_us is not None:
+            res["cold_first_launch_us"] = cold_us
+        return res
 
-    main_res = measure(args.workload, args.steps, args.warmup)
+    main_res = measure(args.workload, args.steps, args.warmup, cold=True)
     others = []
     if not args.no_extras:
         for name in WORKLOADS:
@@ -263,8 +323,15 @@ def main():
                        "height": H_IMG, "width": W_IMG, "knots": "randn*0.1 (160 per image)",
                        "parallelism": f"image-sharded x{world}, no data-path collective"},
             "device_ms_per_step": main_res["device_ms_per_step"],
+            "device_ms_per_step_min_over_ranks": main_res["device_ms_per_step_min_over_ranks"],
+            "cold_first_launch_us": main_res.get("cold_first_launch_us"),
+            "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
+            "ranks_seen": world if dist is None else dist.get_world_size(), "backend": backend,
+            "gpus_visible": n_dev,
             "roofline": main_res["roofline"],
         }
+        if n_dev < world:
+            line["rehearsal"] = f"{world} ranks share {n_dev} GPU(s) over {backend}: not a scaling measurement"
         if not args.no_extras:
             line["other_workloads"] = others
             line["accuracy"] = accuracy_vs_oracle(ops, device)

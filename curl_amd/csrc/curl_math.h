@@ -178,6 +178,34 @@ struct PxN {
   float c0[N], c1[N], c2[N];
 };
 
+// Experiment switches (tools/variants.py; DESIGN.md 5 "dual issue"): gfx950 issues two VALU instructions of
+// different waves in one quad-cycle only when both are plain VGPR/literal-operand instructions -- packed,
+// transcendental and SGPR-operand instructions go alone.
+//   CURL_EXP_PRIO=n : waves raise their issue priority to n while they run pairable code and drop to 0 for the
+//                     packed / transcendental runs, so that the SIMD's pickers see pairable heads together.
+//   CURL_EXP_VCONST : constants and curve coefficients of the scalar FMAs live in VGPRs instead of SGPRs.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CURL_EXP_PRIO)
+#define CURL_SLOW_BEGIN()                \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    __builtin_amdgcn_s_setprio(0);       \
+  } while (0)
+#define CURL_SLOW_END()                          \
+  do {                                           \
+    __builtin_amdgcn_s_setprio(CURL_EXP_PRIO);   \
+    __builtin_amdgcn_sched_barrier(0);           \
+  } while (0)
+#else
+#define CURL_SLOW_BEGIN() ((void)0)
+#define CURL_SLOW_END() ((void)0)
+#endif
+CURL_HD float vconst(float k) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CURL_EXP_VCONST)
+  asm("" : "+v"(k));  // an opaque VGPR value: instructions that use it carry no SGPR operand
+#endif
+  return k;
+}
+
 // Packed FP32: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes-worth of work per instruction at
 // 1.75 ns per SIMD against 2 x 1.07 ns for the scalar forms (tools/ubench/sustained.hip).  hipcc's SLP
 // vectoriser does not form them on its own here, so the element-wise loops over a lane's pixels go through
@@ -207,9 +235,11 @@ CURL_HD void st2(float* a, int i, curl_f2 v) {
 template <int M>
 CURL_HD void fma_run(float (&y)[M], const float (&a)[M], float k, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  CURL_SLOW_BEGIN();
 #pragma unroll
   for (int i = 0; i + 1 < M; i += 2) st2(y, i, __builtin_elementwise_fma(ld2(a, i), splat2(k), splat2(c)));
   if (M & 1) y[M - 1] = fmaf(a[M - 1], k, c);
+  CURL_SLOW_END();
 #else
   for (int i = 0; i < M; ++i) y[i] = fmaf(a[i], k, c);
 #endif
@@ -218,9 +248,11 @@ CURL_HD void fma_run(float (&y)[M], const float (&a)[M], float k, float c) {
 template <int M>
 CURL_HD void mul_run(float (&y)[M], const float (&a)[M], const float (&b)[M]) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  CURL_SLOW_BEGIN();
 #pragma unroll
   for (int i = 0; i + 1 < M; i += 2) st2(y, i, ld2(a, i) * ld2(b, i));
   if (M & 1) y[M - 1] = a[M - 1] * b[M - 1];
+  CURL_SLOW_END();
 #else
   for (int i = 0; i < M; ++i) y[i] = a[i] * b[i];
 #endif
@@ -229,9 +261,11 @@ CURL_HD void mul_run(float (&y)[M], const float (&a)[M], const float (&b)[M]) {
 template <int M>
 CURL_HD void scale_run(float (&y)[M], const float (&a)[M], float k) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  CURL_SLOW_BEGIN();
 #pragma unroll
   for (int i = 0; i + 1 < M; i += 2) st2(y, i, ld2(a, i) * splat2(k));
   if (M & 1) y[M - 1] = a[M - 1] * k;
+  CURL_SLOW_END();
 #else
   for (int i = 0; i < M; ++i) y[i] = a[i] * k;
 #endif
@@ -240,9 +274,11 @@ CURL_HD void scale_run(float (&y)[M], const float (&a)[M], float k) {
 template <int M>
 CURL_HD void rsub_run(float (&y)[M], float k, const float (&a)[M]) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  CURL_SLOW_BEGIN();
 #pragma unroll
   for (int i = 0; i + 1 < M; i += 2) st2(y, i, splat2(k) - ld2(a, i));
   if (M & 1) y[M - 1] = k - a[M - 1];
+  CURL_SLOW_END();
 #else
   for (int i = 0; i < M; ++i) y[i] = k - a[i];
 #endif
@@ -260,13 +296,16 @@ CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, cons
 template <int M>
 CURL_HD void pow_run(float (&x)[M], float e) {
   CURL_FENCE();
+  CURL_SLOW_BEGIN();
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = hw_log2(x[i]);
   CURL_FENCE();
   scale_run(x, x, e);
+  CURL_SLOW_BEGIN();
   CURL_FENCE();
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = hw_exp2(x[i]);
+  CURL_SLOW_END();
   CURL_FENCE();
 }
 
@@ -274,6 +313,7 @@ CURL_HD void pow_run(float (&x)[M], float e) {
 template <int N>
 CURL_HD void mat_row(float (&y)[N], const float (&a)[3 * N], float m0, float m1, float m2) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  CURL_SLOW_BEGIN();
 #pragma unroll
   for (int i = 0; i + 1 < N; i += 2) {
     curl_f2 acc = splat2(m0) * ld2(a, i);
@@ -282,6 +322,7 @@ CURL_HD void mat_row(float (&y)[N], const float (&a)[3 * N], float m0, float m1,
     st2(y, i, acc);
   }
   if (N & 1) y[N - 1] = fmaf(m2, a[3 * N - 1], fmaf(m1, a[2 * N - 1], m0 * a[N - 1]));
+  CURL_SLOW_END();
 #else
   for (int i = 0; i < N; ++i) y[i] = fmaf(m2, a[2 * N + i], fmaf(m1, a[N + i], m0 * a[i]));
 #endif
@@ -329,9 +370,9 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     float fx = f[i], fy = f[N + i], fz = f[2 * N + i];
-    p.c0[i] = fmaf(fy, 1.16f, -0.16f);
-    p.c1[i] = fmaf(fx - fy, (float)(500.0 / 220.0), 0.5f);
-    p.c2[i] = fmaf(fy - fz, (float)(200.0 / 220.0), 0.5f);
+    p.c0[i] = fmaf(fy, vconst(1.16f), vconst(-0.16f));
+    p.c1[i] = fmaf(fx - fy, vconst((float)(500.0 / 220.0)), 0.5f);
+    p.c2[i] = fmaf(fy - fz, vconst((float)(200.0 / 220.0)), 0.5f);
   }
 }
 
@@ -343,9 +384,9 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   for (int i = 0; i < N; ++i) {
     // colors.py:97-99 (L*100, (a*2-1)*110, (b*2-1)*110) and colors.py:79-81,104-106
     // (fy = (L+16)/116, fx = fy + a/500, fz = fy - b/200) with the constants folded:
-    float fy = fmaf(p.c0[i], (float)(100.0 / 116.0), (float)(16.0 / 116.0));
-    float fx = fmaf(p.c1[i], (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0));
-    float fz = fmaf(p.c2[i], (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0));
+    float fy = fmaf(p.c0[i], vconst((float)(100.0 / 116.0)), vconst((float)(16.0 / 116.0)));
+    float fx = fmaf(p.c1[i], vconst((float)(220.0 / 500.0)), fy - (float)(110.0 / 500.0));
+    float fz = fmaf(p.c2[i], vconst((float)(-220.0 / 200.0)), fy + (float)(110.0 / 200.0));
     X[i] = fx, X[N + i] = fy, X[2 * N + i] = fz;
   }
   {
@@ -387,8 +428,8 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     for (int i = 0; i < N; ++i) g[i] = g0[i], lin[i] = l0[i];
 #pragma unroll
     for (int i = N; i < 3 * N; ++i) {
-      g[i] = clamp01(fmaf(g[i], 1.055f, -0.055f));
-      lin[i] = clamp01(v[i] * 12.92f);
+      g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
+      lin[i] = clamp01(v[i] * vconst(12.92f));
     }
 #pragma unroll
     for (int i = 0; i < 3 * N; ++i) v[i] = blend(neg_mask(d[i]), g[i], lin[i]);
@@ -440,7 +481,7 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
     // (not fract(h/6): two channels tying for the maximum at g == b add up to h6 = 6 exactly, which must stay
     // hue 1.0, not wrap to 0 -- the hue curves of adjust_hsv are not periodic)
-    if (UNIT) h = fmaf(h, (float)(1.0 / 6.0), keep_if(neg_mask(h), 1.0f));
+    if (UNIT) h = fmaf(h, vconst((float)(1.0 / 6.0)), keep_if(neg_mask(h), 1.0f));
     else h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
     float s = keep_if(live, nd[i] * (rdm[i] * nd[i]));  // colors.py:234-237: df/mx (0 when df == 0)
     p.c0[i] = UNIT ? h : clampf(h, kHsvFloor, 1.0f);  // colors.py:240
@@ -475,7 +516,7 @@ template <bool UNIT = false>  // UNIT: h, s, v already in [0,1] (straight out of
 CURL_HD Px hsv2rgb(Px p) {
   // colors.py:141-175 in sextant units: clamp(360h - a, 0, 60) * (d/60) == clamp(6h - a/60, 0, 1) * d,
   // so every ramp is one saturating add (v_add_f32 ... clamp) and the /60 disappears.
-  float h = (UNIT ? p.c0 : clamp01(p.c0)) * 6.0f, s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
+  float h = (UNIT ? p.c0 : clamp01(p.c0)) * vconst(6.0f), s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
   float q = v * (1.0f - s);
   float d = v - q;
   // the reference's identically-zero terms (m1,m3,m5 = 0) add +0 and are dropped

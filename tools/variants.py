@@ -24,6 +24,11 @@ VARIANTS = {
     "nodep": ["-DCURL_DIAG_NO_DEP"],
     # scheduling fences around the transcendental runs removed
     "nofence": ["-DCURL_NO_FENCE"],
+    # dual-issue experiments (curl_math.h): issue priority by phase, constants / coefficients in VGPRs
+    "prio1": ["-DCURL_EXP_PRIO=1"],
+    "prio3": ["-DCURL_EXP_PRIO=3"],
+    "vconst": ["-DCURL_EXP_VCONST"],
+    "vconst_prio1": ["-DCURL_EXP_VCONST", "-DCURL_EXP_PRIO=1"],
 }
 
 
