@@ -65,70 +65,171 @@ class CURLLayer(nn.Module):
         return ops.curl_layer_forward(img, mask, L, R, H)
 
 
-def _conv_bn_act(cin, cout, k, stride, groups=1):
-    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=False),
-                         nn.BatchNorm2d(cout), nn.SiLU(inplace=True))
+# ---------------------------------------------------------------------------------------------------------
+# Encoder: EfficientNetV2 (timm's `efficientnetv2_rw_t` / `efficientnetv2_rw_s`, model.py:189,427,456) with timm's
+# module names, so that a checkpoint saved by the reference (main.py:332-338) loads key for key.  timm itself is
+# not installed here (and the reference asks it for a weight download); the architecture is restated from its
+# published definition (timm 0.5.4, efficientnet.py `_gen_efficientnetv2_s`, efficientnet_blocks.py).
+# Stock PyTorch-ROCm ops only (MIOpen convolutions): the encoder is not part of the hand-written path.
+# ---------------------------------------------------------------------------------------------------------
+def _make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
 
 
-class _FusedMBConv(nn.Module):
-    def __init__(self, cin, cout, stride, expand):
+def _conv(cin, cout, k, stride=1, groups=1, bias=False):
+    return nn.Conv2d(cin, cout, k, stride, ((stride - 1) + (k - 1)) // 2, groups=groups, bias=bias)
+
+
+class _ConvBnAct(nn.Module):
+    """timm ConvBnAct ('cn'): conv, bn1, act1 (+ skip)."""
+
+    def __init__(self, cin, cout, k, stride, skip):
         super().__init__()
-        mid = cin * expand
-        self.use_res = stride == 1 and cin == cout
-        self.body = nn.Sequential(_conv_bn_act(cin, mid, 3, stride),
-                                  nn.Conv2d(mid, cout, 1, bias=False), nn.BatchNorm2d(cout))
+        self.has_residual = skip and stride == 1 and cin == cout
+        self.conv = _conv(cin, cout, k, stride)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.act1 = nn.SiLU(inplace=True)
 
     def forward(self, x):
-        y = self.body(x)
-        return x + y if self.use_res else y
+        y = self.act1(self.bn1(self.conv(x)))
+        return y + x if self.has_residual else y
 
 
-class _MBConv(nn.Module):
-    def __init__(self, cin, cout, stride, expand):
+class _SqueezeExcite(nn.Module):
+    """timm SqueezeExcite: conv_reduce, act1, conv_expand, gate."""
+
+    def __init__(self, chs, rd_channels):
         super().__init__()
-        mid = cin * expand
-        self.use_res = stride == 1 and cin == cout
-        self.expand = _conv_bn_act(cin, mid, 1, 1)
-        self.dw = _conv_bn_act(mid, mid, 3, stride, groups=mid)
-        se = max(8, cin // 4)
-        self.se = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(mid, se, 1), nn.SiLU(inplace=True),
-                                nn.Conv2d(se, mid, 1), nn.Sigmoid())
-        self.project = nn.Sequential(nn.Conv2d(mid, cout, 1, bias=False), nn.BatchNorm2d(cout))
+        self.conv_reduce = nn.Conv2d(chs, rd_channels, 1, bias=True)
+        self.act1 = nn.SiLU(inplace=True)
+        self.conv_expand = nn.Conv2d(rd_channels, chs, 1, bias=True)
+        self.gate = nn.Sigmoid()
 
     def forward(self, x):
-        y = self.dw(self.expand(x))
-        y = self.project(y * self.se(y))
-        return x + y if self.use_res else y
+        s = x.mean((2, 3), keepdim=True)
+        return x * self.gate(self.conv_expand(self.act1(self.conv_reduce(s))))
 
 
-class CurveEncoder(nn.Module):
-    """EfficientNetV2-style CNN with a `num_features`-wide pooled output and a `classifier` head,
-    standing in for timm's `efficientnetv2_rw_s` (model.py:189; timm is not installed here and its
-    pretrained weights need a download).  Stock PyTorch-ROCm ops only (MIOpen convolutions)."""
+class _EdgeResidual(nn.Module):
+    """timm EdgeResidual ('er', FusedMBConv): conv_exp (k x k), bn1, act1, se, conv_pwl (1 x 1), bn2."""
 
-    def __init__(self, num_outputs=160, width=1.0, num_features=1792):
+    def __init__(self, cin, cout, k, stride, exp_ratio):
         super().__init__()
+        mid = _make_divisible(cin * exp_ratio)
+        self.has_residual = stride == 1 and cin == cout
+        self.conv_exp = _conv(cin, mid, k, stride)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.act1 = nn.SiLU(inplace=True)
+        self.se = nn.Identity()
+        self.conv_pwl = _conv(mid, cout, 1)
+        self.bn2 = nn.BatchNorm2d(cout)
 
-        def c(v):
-            return max(8, int(v * width + 4) // 8 * 8)
+    def forward(self, x):
+        y = self.bn2(self.conv_pwl(self.se(self.act1(self.bn1(self.conv_exp(x))))))
+        return y + x if self.has_residual else y
 
-        cfg = [  # (block, repeats, out, stride, expand)   ~ efficientnetv2_rw_s stages
-            (_FusedMBConv, 2, c(24), 1, 1), (_FusedMBConv, 4, c(48), 2, 4), (_FusedMBConv, 4, c(64), 2, 4),
-            (_MBConv, 6, c(128), 2, 4), (_MBConv, 9, c(160), 1, 6), (_MBConv, 15, c(272), 2, 6)]
-        layers = [_conv_bn_act(3, c(24), 3, 2)]
-        cin = c(24)
-        for block, n, cout, stride, expand in cfg:
-            for i in range(n):
-                layers.append(block(cin, cout, stride if i == 0 else 1, expand))
+
+class _InvertedResidual(nn.Module):
+    """timm InvertedResidual ('ir', MBConv): conv_pw, bn1, act1, conv_dw, bn2, act2, se, conv_pwl, bn3."""
+
+    def __init__(self, cin, cout, k, stride, exp_ratio, se_ratio):
+        super().__init__()
+        mid = _make_divisible(cin * exp_ratio)
+        self.has_residual = stride == 1 and cin == cout
+        self.conv_pw = _conv(cin, mid, 1)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.act1 = nn.SiLU(inplace=True)
+        self.conv_dw = _conv(mid, mid, k, stride, groups=mid)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.act2 = nn.SiLU(inplace=True)
+        # the builder rescales se_ratio by 1/exp_ratio (reduction counted from the block's input), rounds with round()
+        self.se = _SqueezeExcite(mid, round(mid * se_ratio / exp_ratio)) if se_ratio else nn.Identity()
+        self.conv_pwl = _conv(mid, cout, 1)
+        self.bn3 = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        y = self.act1(self.bn1(self.conv_pw(x)))
+        y = self.se(self.act2(self.bn2(self.conv_dw(y))))
+        y = self.bn3(self.conv_pwl(y))
+        return y + x if self.has_residual else y
+
+
+# (block, repeats, kernel, stride, expansion, channels, se_ratio)
+_V2_ARCH = {
+    # _gen_efficientnetv2_s(rw=False): efficientnetv2_rw_t = channel_multiplier 0.8, depth_multiplier 0.9
+    "efficientnetv2_rw_t": dict(stages=[("cn", 2, 3, 1, 1, 24, 0), ("er", 4, 3, 2, 4, 48, 0), ("er", 4, 3, 2, 4, 64, 0),
+                                        ("ir", 6, 3, 2, 4, 128, 0.25), ("ir", 9, 3, 1, 6, 160, 0.25),
+                                        ("ir", 15, 3, 2, 6, 256, 0.25)],
+                                channel_multiplier=0.8, depth_multiplier=0.9, num_features=1280, stem_size=24),
+    # _gen_efficientnetv2_s(rw=True): first stage 'er', last stage 272 channels, 1792 features
+    "efficientnetv2_rw_s": dict(stages=[("er", 2, 3, 1, 1, 24, 0), ("er", 4, 3, 2, 4, 48, 0), ("er", 4, 3, 2, 4, 64, 0),
+                                        ("ir", 6, 3, 2, 4, 128, 0.25), ("ir", 9, 3, 1, 6, 160, 0.25),
+                                        ("ir", 15, 3, 2, 6, 272, 0.25)],
+                                channel_multiplier=1.0, depth_multiplier=1.0, num_features=1792, stem_size=24),
+}
+
+
+class EfficientNetV2(nn.Module):
+    """timm.models.efficientnet.EfficientNet for the two V2 variants the reference builds: same module tree
+    (conv_stem, bn1, act1, blocks.<stage>.<index>.*, conv_head, bn2, act2, global_pool, classifier), same shapes.
+    `channel_multiplier` / `num_features` can be overridden to get a small encoder for tests."""
+
+    def __init__(self, variant="efficientnetv2_rw_t", num_classes=1000, channel_multiplier=None, depth_multiplier=None,
+                 num_features=None):
+        super().__init__()
+        import math
+        cfg = _V2_ARCH[variant]
+        cm = cfg["channel_multiplier"] if channel_multiplier is None else channel_multiplier
+        dm = cfg["depth_multiplier"] if depth_multiplier is None else depth_multiplier
+
+        def chs(c):
+            return _make_divisible(c * cm)
+
+        stem = chs(cfg["stem_size"])
+        self.conv_stem = _conv(3, stem, 3, 2)
+        self.bn1 = nn.BatchNorm2d(stem)
+        self.act1 = nn.SiLU(inplace=True)
+        stages, cin = [], stem
+        for kind, reps, k, stride, exp, c, se in cfg["stages"]:
+            cout, blocks = chs(c), []
+            for i in range(int(math.ceil(reps * dm))):
+                st = stride if i == 0 else 1
+                if kind == "cn":
+                    blocks.append(_ConvBnAct(cin, cout, k, st, skip=True))
+                elif kind == "er":
+                    blocks.append(_EdgeResidual(cin, cout, k, st, exp))
+                else:
+                    blocks.append(_InvertedResidual(cin, cout, k, st, exp, se))
                 cin = cout
-        layers.append(_conv_bn_act(cin, num_features, 1, 1))
-        self.features = nn.Sequential(*layers)
-        self.pool = nn.AdaptiveAvgPool2d(1)
-        self.num_features = num_features
-        self.classifier = nn.Linear(num_features, num_outputs)
+            stages.append(nn.Sequential(*blocks))
+        self.blocks = nn.Sequential(*stages)
+        self.num_features = chs(cfg["num_features"]) if num_features is None else num_features
+        self.conv_head = _conv(cin, self.num_features, 1)
+        self.bn2 = nn.BatchNorm2d(self.num_features)
+        self.act2 = nn.SiLU(inplace=True)
+        self.global_pool = nn.AdaptiveAvgPool2d(1)
+        self.classifier = nn.Linear(self.num_features, num_classes)
+
+    def forward_features(self, x):
+        x = self.act1(self.bn1(self.conv_stem(x)))
+        x = self.blocks(x)
+        return self.act2(self.bn2(self.conv_head(x)))
 
     def forward(self, x):
-        return self.classifier(self.pool(self.features(x)).flatten(1))
+        return self.classifier(self.global_pool(self.forward_features(x)).flatten(1))
+
+
+class CurveEncoder(EfficientNetV2):
+    """The encoder GCURLNet / PolyRegNet regress from: timm's `efficientnetv2_rw_s` (model.py:189,427) by default, with a
+    `num_outputs`-wide linear head.  `width` scales the channels (tests and the smoke run use a narrow one)."""
+
+    def __init__(self, num_outputs=160, width=1.0, num_features=1792, variant="efficientnetv2_rw_s"):
+        super().__init__(variant, num_classes=num_outputs, channel_multiplier=_V2_ARCH[variant]["channel_multiplier"] * width,
+                         num_features=num_features)
 
 
 class GCURLNet(nn.Module):
@@ -307,8 +408,9 @@ class TriSpaceRegNet(nn.Module):
         self.num_coeffs = self.polylayer.num_coeffs
         if self.order != 4 or self.num_coeffs not in (126, 35):
             raise NotImplementedError("fused kernel: polynomial_order 4 with spatial=True (126) or False (35)")
-        if backbone is None:
-            backbone = CurveEncoder(num_outputs=1, num_features=feature_width)
+        if backbone is None:  # model.py:456: timm.create_model('efficientnetv2_rw_t')
+            backbone = EfficientNetV2("efficientnetv2_rw_t") if feature_width == 1024 else \
+                CurveEncoder(num_outputs=1, num_features=feature_width, variant="efficientnetv2_rw_t")
         if use_sync_bn:
             backbone = nn.SyncBatchNorm.convert_sync_batchnorm(backbone)  # model.py:457-458
         backbone.classifier = nn.Sequential(  # model.py:459-463
@@ -318,6 +420,20 @@ class TriSpaceRegNet(nn.Module):
         self.rgb2lab, self.lab2rgb = colors.RGB2LAB(), colors.LAB2RGB()
         self.rgb2hsv, self.hsv2rgb = colors.RGB2HSV(), colors.HSV2RGB()
         self.sigmoid = nn.Sigmoid()
+        # model.py:476-484: the coordinate ramps are frozen nn.Parameters, hence state-dict keys `x` and `y` of every
+        # reference checkpoint (int64 arange for spatial=True, zero-width float for spatial=False).  The fused kernel
+        # forms column/width and row/height itself; the parameters exist so that checkpoints load key for key.
+        if not spatial:
+            x, y = torch.zeros(1, 0, 1, self.max_resolution), torch.zeros(1, 0, self.max_resolution, 1)
+        else:
+            x = torch.arange(0, self.max_resolution).reshape(1, 1, 1, self.max_resolution)
+            y = torch.arange(0, self.max_resolution).reshape(1, 1, self.max_resolution, 1)
+        self.x = nn.Parameter(x, requires_grad=False)
+        self.y = nn.Parameter(y, requires_grad=False)
+
+    def _check_resolution(self, img):
+        assert img.shape[2] <= self.max_resolution and img.shape[3] <= self.max_resolution, \
+            "img width and height must be less than `max_resolution`, set for instance to: {}".format(self.max_resolution)
 
     def generate_coefficients(self, img, mask):
         """model.py:522-527."""
@@ -326,6 +442,7 @@ class TriSpaceRegNet(nn.Module):
 
     def generate_residual(self, img, R, L, H):
         """model.py:499-515, one kernel (differentiable w.r.t. R, L, H)."""
+        self._check_resolution(img)  # model.py:491
         coeffs = torch.stack((R, L, H), 1)
         if torch.is_grad_enabled() and coeffs.requires_grad:
             return _TriSpaceFn.apply(img, coeffs, True)
@@ -341,6 +458,7 @@ class TriSpaceRegNet(nn.Module):
         is_train=True returns the image clamp(input + residual), else the residual."""
         coeffs = self.backbone(img * mask).reshape(img.shape[0], self.num_spaces, self.num_channels, self.num_coeffs)
         input_img = img if target_img is None else target_img
+        self._check_resolution(input_img)  # model.py:491
         if torch.is_grad_enabled() and coeffs.requires_grad:
             return _TriSpaceFn.apply(input_img, coeffs, not self.is_train)
         return ops.trispace_forward(input_img, coeffs, residual_only=not self.is_train)

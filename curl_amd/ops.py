@@ -44,6 +44,46 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _check_same_device(named):
+    """Every tensor of one call must live on ONE device: a knot / mask / gradient tensor on cuda:1 next to an image on
+    cuda:0 would hand the kernel a foreign pointer (a GPU fault) where the reference's eager ops raise cleanly."""
+    devs = [(n, t.device) for n, t in named if isinstance(t, torch.Tensor)]
+    cuda = [(n, d) for n, d in devs if d.type == "cuda"]
+    if len({d for _, d in cuda}) > 1:
+        raise ValueError("expected all tensors to be on the same device, got " +
+                         ", ".join(f"{n} on {d}" for n, d in cuda))
+    return cuda[0][1] if cuda and len(cuda) == len(devs) else None
+
+
+def _one_device(fn):
+    """Check that all tensor arguments share a device and run the call with that device current (the library
+    enqueues on the stream it is handed and never calls hipSetDevice itself)."""
+    import inspect
+    params = list(inspect.signature(fn).parameters)
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        named = list(zip(params, args)) + list(kwargs.items())
+        dev = _check_same_device(named)
+        if dev is None:  # a CPU tensor (or none at all): the body's own checks raise the documented errors
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def _check_out(out, img):
+    """A caller-supplied `out` is written in place by the kernel: anything but a contiguous float32 tensor of the
+    image's shape on the image's device would be an out-of-bounds or foreign-device write."""
+    if not isinstance(out, torch.Tensor):
+        raise TypeError(f"out must be a torch.Tensor, got {type(out).__name__}")
+    if out.shape != img.shape or out.dtype != img.dtype or not out.is_contiguous() or out.device != img.device:
+        raise ValueError(f"out must be a contiguous {img.dtype} tensor of shape {tuple(img.shape)} on {img.device}, got "
+                         f"{out.dtype} {tuple(out.shape)} on {out.device}"
+                         f"{'' if out.is_contiguous() else ' (not contiguous)'}")
+    return out
+
+
 def _need_device(t, name):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
@@ -109,6 +149,7 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------ curves.py
+@_one_device
 @_empty_ok(mask_arg=-1)
 def apply_curve(img, C, slope_sqr_diff, channel_in, channel_out, flags=F_EXACT_ORDER):
     """curves.apply_curve (curves.py:4-38).  C are the knots after exp, [B,K].
@@ -143,18 +184,21 @@ def _adjust(fn_name, ncurves, img, raw, flags):  # noqa: E302
     return out, reg
 
 
+@_one_device
 @_empty_ok(mask_arg=-1)
 def adjust_rgb(img, R, flags=0):
     """curves.adjust_rgb (curves.py:90-133), regulariser seeded with zeros."""
     return _adjust("curl_adjust_rgb_f32", 3, img, R, flags)
 
 
+@_one_device
 @_empty_ok(mask_arg=-1)
 def adjust_lab(img, L, flags=0):
     """curves.adjust_lab (curves.py:136-180)."""
     return _adjust("curl_adjust_lab_f32", 3, img, L, flags)
 
 
+@_one_device
 @_empty_ok(mask_arg=-1)
 def adjust_hsv(img, S, flags=0):
     """curves.adjust_hsv (curves.py:41-87)."""
@@ -172,24 +216,28 @@ def _convert(fn_name, img, flags=0):
     return out
 
 
+@_one_device
 @_empty_ok()
 def rgb2lab(img, flags=0):
     """colors.RGB2LAB.forward (colors.py:27-62)."""
     return _convert("curl_rgb2lab_f32", img, flags)
 
 
+@_one_device
 @_empty_ok()
 def lab2rgb(img, flags=0):
     """colors.LAB2RGB.forward (colors.py:88-123)."""
     return _convert("curl_lab2rgb_f32", img, flags)
 
 
+@_one_device
 @_empty_ok()
 def rgb2hsv(img, flags=0):
     """colors.RGB2HSV.forward (colors.py:195-242)."""
     return _convert("curl_rgb2hsv_f32", img, flags)
 
 
+@_one_device
 @_empty_ok()
 def hsv2rgb(img, flags=0):
     """colors.HSV2RGB.forward (colors.py:131-177)."""
@@ -197,6 +245,7 @@ def hsv2rgb(img, flags=0):
 
 
 # ------------------------------------------------------------------ model.py: fused stages
+@_one_device
 @_empty_ok(mask_arg=0)
 def lab_stage(img, mask, L, flags=0, out=None):
     """RGB -> Lab -> 3 curves -> *mask -> RGB in one pass (model.py:151-157). -> (rgb, reg_lab)."""
@@ -205,7 +254,7 @@ def lab_stage(img, mask, L, flags=0, out=None):
     B, _, H, W = img.shape
     Lc, Kl = _knots(L, "L", 3, B)
     m, kind = _mask(mask, img)
-    out = torch.empty_like(img) if out is None else out
+    out = torch.empty_like(img) if out is None else _check_out(out, img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
     ws, nbytes = _workspace(B, 3 * Kl, img.device)
     rc = lib.curl_lab_stage_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), out.data_ptr(), reg.data_ptr(),
@@ -214,6 +263,7 @@ def lab_stage(img, mask, L, flags=0, out=None):
     return out, reg
 
 
+@_one_device
 @_empty_ok(mask_arg=0)
 def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     """CURLLayer.forward (model.py:137-176) in one pass over the pixels. -> (img, reg[B]).
@@ -225,8 +275,7 @@ def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     Rc, Kr = _knots(R, "R", 3, B)
     Hc, Kh = _knots(H, "H", 4, B)
     m, kind = _mask(mask, img)
-    if out is None:
-        out = torch.empty_like(img)
+    out = torch.empty_like(img) if out is None else _check_out(out, img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
     ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
     rc = lib.curl_layer_fwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
@@ -236,6 +285,7 @@ def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     return out, reg
 
 
+@_one_device
 def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True):
     """Backward of curl_layer_forward (what autograd would run through model.py:137-176).
     -> (grad_img or None, grad_L, grad_R, grad_H)."""
@@ -268,6 +318,7 @@ def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_i
 
 
 # ------------------------------------------------------------------ polynomial path (model.py:206-520)
+@_one_device
 @_empty_ok()
 def trispace_forward(img, coeffs, residual_only=False, flags=0):
     """TriSpaceRegNet.generate_residual (+ generate_image unless residual_only), model.py:499-520, in one pass.
@@ -286,6 +337,7 @@ def trispace_forward(img, coeffs, residual_only=False, flags=0):
     return out
 
 
+@_one_device
 def trispace_backward(img, coeffs, grad_out, residual_only=False):
     """d loss / d coeffs [B,3,3,NC] of trispace_forward, given grad_out = d loss / d out."""
     lib = _lib.load()
@@ -302,6 +354,7 @@ def trispace_backward(img, coeffs, grad_out, residual_only=False):
     return g
 
 
+@_one_device
 def poly_layer(img, coeffs):
     """ChannelPolyLayer(degree=4) / Deg4MobilePolyLayer forward (model.py:295-333, 399-415):
     img [B,V,H,W] with V = 5 or 3, coeffs [B,3,126|35] -> [B,3,H,W]."""
@@ -322,6 +375,7 @@ def poly_layer(img, coeffs):
 
 
 # ------------------------------------------------------------------ layout edges
+@_one_device
 def u8hwc_to_f32chw(x):
     """uint8 [B,H,W,3|4] (or [H,W,C]) -> float32 [B,3,H,W] = value/255 (infer.py:35-40, transpose.py:19-31)."""
     lib = _lib.load()
@@ -340,6 +394,7 @@ def u8hwc_to_f32chw(x):
     return out[0] if squeeze else out
 
 
+@_one_device
 def f32chw_to_u8hwc(x):
     """float32 [B,3,H,W] (or [3,H,W]) -> uint8 [B,H,W,3], (x*255) TRUNCATED (evaluate.py:64-66)."""
     lib = _lib.load()
@@ -353,6 +408,7 @@ def f32chw_to_u8hwc(x):
     return out[0] if squeeze else out
 
 
+@_one_device
 def compose_white_u8hwc(x, mask):
     """infer.py:46-47 in one pass: x*mask + (1-mask), then (.*255) truncated to uint8, CHW -> HWC."""
     lib = _lib.load()
@@ -388,6 +444,7 @@ def _white(white_mask, img_u8):
     return white_mask.contiguous()
 
 
+@_one_device
 def trispace_forward_u8hwc(img_u8, coeffs, white_mask=None):
     """infer.py:35-47 on the file's own bytes, one launch: byte/255 -> generate_residual + generate_image ->
     [out*m + (1-m), m = white_mask/255] -> truncating *255.  img_u8 [B,H,W,3] uint8 -> [B,H,W,3] uint8."""
@@ -406,6 +463,7 @@ def trispace_forward_u8hwc(img_u8, coeffs, white_mask=None):
     return out
 
 
+@_one_device
 def curl_layer_forward_u8hwc(img_u8, mask, L, R, H, white_mask=None):
     """CURLLayer.forward between byte images: byte/255 -> the layer (mask [B,1,H,W] as in curl_layer_forward) ->
     [white background] -> truncating *255.  -> (uint8 [B,H,W,3], reg [B])."""
@@ -434,6 +492,7 @@ def _planes(t, name):
     return t.contiguous()
 
 
+@_one_device
 def msssim_stats(a, b, window_size=11):
     """MSSSIMMetric.compute_ssim over the five pyramid levels (metric.py:120-166,185-192) in five launches.
     a, b [B,C,H,W] -> (ssims [B,5], mcs [B,5]): per level, the per-image means of the SSIM and contrast-structure maps."""
@@ -452,6 +511,7 @@ def msssim_stats(a, b, window_size=11):
     return ssims, mcs
 
 
+@_one_device
 def msssim_stats_backward(a, b, g_ssims, g_mcs, window_size=11):
     """d loss / d a of msssim_stats, given d loss / d ssims and d loss / d mcs ([B,5] each)."""
     lib = _lib.load()
@@ -468,6 +528,7 @@ def msssim_stats_backward(a, b, g_ssims, g_mcs, window_size=11):
     return grad
 
 
+@_one_device
 def psnr_per_image(a, b, mask=None, max_intensity=1.0):
     """metric.py:35-62 per image: masked PSNR [B] (NaN where an image has no unmasked pixel or zero error -> inf)."""
     lib = _lib.load()
@@ -485,6 +546,7 @@ def psnr_per_image(a, b, mask=None, max_intensity=1.0):
     return out
 
 
+@_one_device
 def loss_term_sums(pred, target, mask, want_L=True):
     """Per-image sums of the CURLLoss pointwise terms (model.py:89-109): [B,5] float64 =
     (sum|p-t|, sum cos_sim, sum|lab|, sum|hsv cone|, sum mask), plus the clamped L planes for MS-SSIM."""
@@ -505,6 +567,7 @@ def loss_term_sums(pred, target, mask, want_L=True):
     return sums, Lp, Lt
 
 
+@_one_device
 def loss_terms_backward(pred, target, mask, weights, grad_L_pred=None):
     """d(sum_k weights[k] * sum_k-th pointwise sum + <grad_L_pred, L_pred>) / d pred.  weights: device float32 [4]."""
     lib = _lib.load()

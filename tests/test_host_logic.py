@@ -200,3 +200,71 @@ def test_folder_dataset_mirror(tmp_path):
     x = torch.arange(3 * 8 * 8, dtype=torch.float32).reshape(3, 8, 8)
     r = data._rotate_nearest(x, 90.0)
     assert torch.equal(r, torch.rot90(x, 1, (1, 2))) or torch.equal(r, torch.rot90(x, -1, (1, 2)))
+
+
+def test_bench_gpus_n_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks as a child process (torch.distributed.run,
+    127.0.0.1 rendezvous) before touching the GPU, and refuses a WORLD_SIZE that contradicts --gpus."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7  # the child's return code is ours
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher with the wrong world size: loud exit, not a silent 1-rank run
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(bench.torch.cuda, "set_device", lambda d: None)
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: None)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE 2" in str(e.value.code)
+
+
+def test_ops_refuse_tensors_on_different_devices():
+    """A knot / mask / out tensor on another GPU than the image must raise, not reach the kernel."""
+    from unittest.mock import MagicMock
+
+    def fake(dev):
+        t = MagicMock(spec=torch.Tensor)
+        t.device = torch.device(dev)
+        return t
+    a, b = fake("cuda:0"), fake("cuda:1")
+    with pytest.raises(ValueError, match="same device"):
+        ops._check_same_device([("img", a), ("L", b)])
+    with pytest.raises(ValueError, match="L on cuda:1"):
+        ops.curl_layer_forward(a, None, b, a, a)           # through the public entry point's decorator
+    assert ops._check_same_device([("img", a), ("mask", None), ("R", fake("cuda:0"))]) == torch.device("cuda:0")
+    assert ops._check_same_device([("img", torch.zeros(1)), ("R", a)]) is None   # CPU tensor: the body raises
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ops.rgb2lab(torch.zeros(1, 3, 4, 4))
+
+
+def test_out_argument_is_validated():
+    img = torch.zeros(2, 3, 8, 8)
+    assert ops._check_out(torch.empty_like(img), img).shape == img.shape
+    for bad in (torch.empty(2, 3, 8, 4), torch.empty(2, 3, 8, 8, dtype=torch.float64),
+                torch.empty(2, 3, 8, 16)[..., ::2], torch.empty(2, 3, 8, 8, device="meta")):
+        with pytest.raises(ValueError, match="out must be"):
+            ops._check_out(bad, img)
+    with pytest.raises(TypeError):
+        ops._check_out([1, 2], img)

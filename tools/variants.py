@@ -29,6 +29,15 @@ VARIANTS = {
     "prio3": ["-DCURL_EXP_PRIO=3"],
     "vconst": ["-DCURL_EXP_VCONST"],
     "vconst_prio1": ["-DCURL_EXP_VCONST", "-DCURL_EXP_PRIO=1"],
+    # the other way round: the UNPAIRABLE runs (transcendental, packed) at raised priority
+    "ps_t1": ["-DCURL_PRIO_TRANS=1"],
+    "ps_tp1": ["-DCURL_PRIO_TRANS=1", "-DCURL_PRIO_PK=1"],
+    "ps_t2p1": ["-DCURL_PRIO_TRANS=2", "-DCURL_PRIO_PK=1"],
+    "ps_tp3": ["-DCURL_PRIO_TRANS=3", "-DCURL_PRIO_PK=3"],
+    "ps_p1": ["-DCURL_PRIO_PK=1"],
+    # packed-FP32 helpers as scalar loops (plain instructions can pair, packed ones cannot)
+    "nopk": ["-DCURL_NO_PK"],
+    "nopk_t1": ["-DCURL_NO_PK", "-DCURL_PRIO_TRANS=1"],
 }
 
 
