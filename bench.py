@@ -168,6 +168,15 @@ def accuracy_vs_oracle(ops, device):
     noise = (ref.double() - ref64).abs()      # the reference's own float32 rounding on this frame
     ours = (out.double() - ref64).abs()       # the HIP result against float64 truth
     over = d > 1e-5
+    # conditioning of the chain per pixel: max |d out / d in| of the float64 evaluation (finite differences)
+    S = torch.zeros(1, H_IMG, W_IMG, dtype=torch.float64)
+    for k in range(3):
+        for sgn in (1e-6, -1e-6):
+            p = img.double().clone()
+            p[:, k] += sgn
+            o, _ = O.curl_layer(p, mf.double(), L.double(), R.double(), Hk.double())
+            S = torch.maximum(S, (o - ref64).abs().amax(1) / 1e-6)
+    S3 = S[:, None].expand_as(d)
     mse = float((d ** 2).sum() / (3 * mf.sum()))
     psnr_vs_ref = float("inf") if mse == 0 else 10 * torch.log10(torch.tensor(1.0 / mse)).item()
     p_out, p_ref = O.psnr(out, gt, mf), O.psnr(ref, gt, mf)
@@ -181,6 +190,11 @@ def accuracy_vs_oracle(ops, device):
         "ours_vs_f64_frac_over_1e-5": float((ours > 1e-5).double().mean()),
         "frac_of_over_1e-5_px_where_ref_noise_over_2.5e-6": (float((noise[over] > 2.5e-6).double().mean())
                                                               if bool(over.any()) else None),
+        # tests/test_gpu_parity.py::test_fullsize_exception_set_is_pinned_by_conditioning: error <= max(1e-5, 2e-6 * S)
+        "min_sensitivity_where_err_over_1e-5": float(S3[over].min()) if bool(over.any()) else None,
+        "max_err_per_unit_sensitivity": float((d / S3.clamp_min(5.0)).max()),
+        "ref_self_noise_per_unit_sensitivity": float((noise / S3.clamp_min(5.0)).max()),
+        "frac_px_sensitivity_over_5": float((S > 5.0).double().mean()),
         "psnr_out_vs_ref_db": psnr_vs_ref,
         "psnr_delta_db": abs(float(p_out) - float(p_ref)),
         "reg_rel_err": float(((reg.cpu() - ref_reg).abs() / ref_reg.abs()).max()),

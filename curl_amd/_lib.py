@@ -41,10 +41,13 @@ SIGNATURES = {
     "curl_lab_stage_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
     "curl_layer_fwd_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz,
                                 _i, _i, _i, _i, _i, _i, _u, _c_f]),
+    "curl_layer_fwd_slab_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz,
+                                     _i, _i, _i, _i, _i, _i, _i, _i, _u, _c_f]),
     "curl_layer_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "curl_layer_bwd_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                 _c_f, _sz, _c_f, _sz, _i, _i, _i, _i, _i, _i, _u, _c_f]),
     "curl_trispace_fwd_f32": (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _u, _c_f]),
+    "curl_trispace_fwd_slab_f32": (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _u, _c_f]),
     "curl_trispace_fwd_u8hwc": (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _u, _c_f]),
     "curl_layer_fwd_u8hwc": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _i, _i,
                                   _u, _c_f]),

@@ -60,8 +60,10 @@ class Dataset(torch.utils.data.Dataset):
         self.is_train = is_train
         self.crop_h, self.crop_w = crop_h, crop_w
         self.rng = torch.Generator()
+        self.seed = seed
         if seed is not None:
             self.rng.manual_seed(seed)
+        self._worker_seed = None
 
     def __len__(self):
         return len(self.data_dict.keys())
@@ -79,6 +81,14 @@ class Dataset(torch.utils.data.Dataset):
         return img.astype('float32') / normaliser
 
     def _rand(self):
+        # Every DataLoader worker starts from a COPY of this object: with a private generator alone all workers would
+        # draw the same crop / flip / rotation stream, and every epoch (workers are recreated from the parent's
+        # never-advanced copy) would replay it.  The reference draws from the global RNG, which DataLoader reseeds per
+        # worker and per epoch (base_seed + worker id); the private generator is re-seeded from that same seed.
+        info = torch.utils.data.get_worker_info()
+        if info is not None and self._worker_seed != info.seed:
+            self.rng.manual_seed((info.seed + 0x9E3779B97F4A7C15 * ((self.seed or 0) + 1)) % (1 << 63))
+            self._worker_seed = info.seed
         return float(torch.rand((), generator=self.rng))
 
     def _crop(self, x):

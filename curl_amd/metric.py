@@ -1,6 +1,8 @@
 """Drop-ins for the reference's metric.py: the masked PSNR (PSNRMetric, metric.py:28-72) on the HIP reduction
-kernels, and MS-SSIM (MSSSIMMetric, metric.py:75-211) -- Gaussian-window convolutions, i.e. stock PyTorch-ROCm
-(MIOpen) like the encoder, not a hand-written kernel; device-agnostic (the reference's `.cuda()` calls are gone)."""
+kernels, and MS-SSIM (MSSSIMMetric, metric.py:75-211): on a HIP device its five-level SSIM statistics run on the
+LDS-tiled stencil kernels of kernels/msssim.inc (forward and backward w.r.t. the first image); the stock-torch
+grouped-conv2d form of the reference remains for CPU tensors, windows larger than 11 and a second image that needs a
+gradient.  Device-agnostic (the reference's `.cuda()` calls are gone)."""
 from math import exp
 
 import torch

@@ -285,6 +285,55 @@ def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     return out, reg
 
 
+def _slab(rows, H):
+    r0, r1 = int(rows[0]), int(rows[1])
+    if not (0 <= r0 < r1 <= H):
+        raise ValueError(f"rows must satisfy 0 <= r0 < r1 <= H={H}, got {rows}")
+    return r0, r1 - r0
+
+
+@_one_device
+def curl_layer_forward_rows(img, mask, L, R, H, rows, out, flags=0):
+    """CURLLayer.forward on rows [r0, r1) of every image of the FULL tensors, in place in `out` (full-size, required):
+    the split-pixels layout (shard.apply_row_slab) without the .contiguous() copy of a row slice.  Rows outside the
+    slab are neither read nor written.  -> (out, reg[B])."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, Hh, W = img.shape
+    r0, n = _slab(rows, Hh)
+    Lc, Kl = _knots(L, "L", 3, B)
+    Rc, Kr = _knots(R, "R", 3, B)
+    Hc, Kh = _knots(H, "H", 4, B)
+    m, kind = _mask(mask, img)
+    out = _check_out(out, img)
+    reg = torch.empty(B, dtype=torch.float32, device=img.device)
+    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
+    rc = lib.curl_layer_fwd_slab_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
+                                     out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, r0, n, Kl, Kr, Kh,
+                                     flags, _stream(img))
+    _lib.check(rc, "curl_layer_fwd_slab_f32")
+    return out, reg
+
+
+@_one_device
+def trispace_forward_rows(img, coeffs, rows, out, residual_only=False):
+    """trispace_forward on rows [r0, r1) of every image of the FULL tensors (pixel coordinates stay the full image's:
+    the rows written equal the same rows of the whole-image call bit for bit)."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, H, W = img.shape
+    r0, n = _slab(rows, H)
+    _need_device(coeffs, "coeffs")
+    if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
+        raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
+    c = coeffs.to(torch.float32).contiguous()
+    out = _check_out(out, img)
+    rc = lib.curl_trispace_fwd_slab_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, r0, n, c.shape[3],
+                                        _lib.F_RESIDUAL_ONLY if residual_only else 0, _stream(img))
+    _lib.check(rc, "curl_trispace_fwd_slab_f32")
+    return out
+
+
 @_one_device
 def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True):
     """Backward of curl_layer_forward (what autograd would run through model.py:137-176).

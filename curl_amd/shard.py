@@ -49,10 +49,43 @@ def allgather_knots(local_knots, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
 
 
-def apply_row_slab(layer, img, mask, L, R, H, rank, world):
-    """Split-pixels layout: apply the layer to this rank's rows of every image. Returns (slab_out, reg, (r0, r1))."""
+def apply_row_slab(layer, img, mask, L, R, H, rank, world, out=None):
+    """Split-pixels layout: apply the curve layer to this rank's rows of every image.  Returns (out, reg, (r0, r1))
+    with `out` a FULL-SIZE tensor (allocated here if not given) whose rows [r0, r1) hold the result.
+
+    On a HIP device the rows are processed in place through the stride-aware entry point
+    (ops.curl_layer_forward_rows -> curl_layer_fwd_slab_f32): no .contiguous() copy of the slab (a row slice of an
+    NCHW tensor is three separate chunks per image), 24-28 B/px like the whole-image call.  `layer` may be a
+    CURLLayer (its knot slicing is applied) or any callable (img, mask, L, R, H) -> (img, reg) for CPU rehearsals,
+    which takes the slice-and-copy route."""
     r0, r1 = row_slab(img.shape[2], rank, world)
+    if out is None:
+        out = torch.empty_like(img)
+    if r1 == r0:  # more ranks than rows: nothing to do here
+        reg = torch.zeros(img.shape[0], dtype=torch.float32, device=img.device)
+        return out, reg, (r0, r1)
+    if img.is_cuda:
+        from . import ops
+        n = [getattr(layer, a, None) for a in ("num_lab_points", "num_rgb_points", "num_hsv_points")]
+        if None not in n:
+            L, R, H = L[:, :n[0]], R[:, :n[1]], H[:, :n[2]]  # model.py:153,159,165
+        _, reg = ops.curl_layer_forward_rows(img, mask, L, R, H, (r0, r1), out)
+        return out, reg, (r0, r1)
     sub = img[:, :, r0:r1, :].contiguous()
     sub_mask = None if mask is None else mask[:, :, r0:r1, :].contiguous()
-    out, reg = layer(sub, sub_mask, L, R, H)
+    o, reg = layer(sub, sub_mask, L, R, H)
+    out[:, :, r0:r1, :] = o
     return out, reg, (r0, r1)
+
+
+def apply_row_slab_trispace(img, coeffs, rank, world, out=None, residual_only=False):
+    """The same layout for the polynomial model (model.py:499-520): rows [r0, r1) of every image through
+    ops.trispace_forward_rows, whose pixel coordinates are the FULL image's (y = row / H with the image's height --
+    slicing the tensor and calling the whole-image entry point would renumber the rows)."""
+    from . import ops
+    r0, r1 = row_slab(img.shape[2], rank, world)
+    if out is None:
+        out = torch.empty_like(img)
+    if r1 > r0:
+        ops.trispace_forward_rows(img, coeffs, (r0, r1), out, residual_only=residual_only)
+    return out, (r0, r1)

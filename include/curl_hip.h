@@ -126,6 +126,19 @@ int curl_layer_fwd_f32(const float* img, const void* mask, int mask_kind,
                        int B, int H, int W, int Kl, int Kr, int Kh,
                        unsigned flags, curl_stream_t stream);
 
+/* The same pass over ROWS [row0, row0 + rows) of every image only -- the shared-encoder / split-pixels layout of
+ * BASELINE.json's north_star: every GPU holds the knots of the whole batch (one RCCL broadcast /
+ * all-gather, 640 B per image) and enhances its row slab of every image.
+ * replaces: CURLLayer.forward(img[:, :, row0:row0+rows], mask[:, :, row0:row0+rows], L, R, H) (model.py:137-176)
+ *           WITHOUT the .contiguous() copy a slice of an NCHW tensor needs: img, mask and out are the base pointers
+ *           of the FULL [B,3,H,W] / [B,1,H,W] tensors; only the slab's rows are read and written (in place is
+ *           allowed), plane stride H*W.  float4 kernels when H*W, row0*W and rows*W are multiples of 4. */
+int curl_layer_fwd_slab_f32(const float* img, const void* mask, int mask_kind,
+                            const float* rawL, const float* rawR, const float* rawH,
+                            float* out, float* reg, void* workspace, size_t workspace_bytes,
+                            int B, int H, int W, int row0, int rows, int Kl, int Kr, int Kh,
+                            unsigned flags, curl_stream_t stream);
+
 /* replaces: torch autograd through CURLLayer.forward (model.py:137-176 over curves.py / colors.py), i.e. what
  *           loss.backward() runs for this layer in main.py:287.  One pass over the pixels (forward chain
  *           recomputed in registers) + a per-image pass for the knots.
@@ -150,6 +163,13 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind,
  * Default output: clamp(img + residual, 0, 1); with CURL_F_RESIDUAL_ONLY the residual itself. */
 int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
                           int num_coeffs, unsigned flags, curl_stream_t stream);
+
+/* Rows [row0, row0 + rows) of every image only (see curl_layer_fwd_slab_f32): img and out are the base pointers of
+ * the full [B,3,H,W] tensors.  The polynomial's coordinates stay those of the FULL image -- cat_coords' y = row /
+ * H (model.py:487-497) with the image's row index and height, not the slab's -- so the rows written are bit-identical
+ * to the same rows of curl_trispace_fwd_f32 on the whole image. */
+int curl_trispace_fwd_slab_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
+                               int row0, int rows, int num_coeffs, unsigned flags, curl_stream_t stream);
 
 /* replaces: the file-to-file inference path of infer.py:35-47 in ONE launch -- TF.to_tensor (byte/255), the
  *           full-resolution generate_residual + generate_image, `out*tmask + (1-tmask)` and to_pil_image's

@@ -37,7 +37,13 @@ def _worker(rank, world, port, n_images, ret):
             return x * L[:, :1].reshape(-1, 1, 1, 1) + 1.0, L.sum(1)
         out, reg, (r0, r1) = shard.apply_row_slab(fake_layer, img, None, buf, buf, buf, rank, world)
         full, _ = fake_layer(img, None, buf, buf, buf)
-        ok_slab = torch.equal(out, full[:, :, r0:r1])
+        # the result comes back as rows [r0, r1) of a FULL-size tensor (what the in-place HIP entry point writes)
+        ok_slab = out.shape == img.shape and torch.equal(out[:, :, r0:r1], full[:, :, r0:r1])
+        # ... so that the slabs of all ranks assemble the whole output with one sum (zero elsewhere)
+        mine = torch.zeros_like(img)
+        mine[:, :, r0:r1] = out[:, :, r0:r1]
+        dist.all_reduce(mine)
+        ok_slab = ok_slab and torch.equal(mine, full)
         rows = torch.tensor([r1 - r0])
         dist.all_reduce(rows)
         ret[rank] = (ok_bcast, ok_gather, float(t), ok_slab, int(rows))

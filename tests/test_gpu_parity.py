@@ -842,3 +842,143 @@ def test_new_entry_points_reject_bad_arguments(ops, dev):
     # and the fused PWL forms need every curve to fit the LDS table
     with pytest.raises(ValueError):
         ops.lab_stage(img, None, torch.zeros(1, 3 * 300, device=dev), flags=_lib.F_PWL)
+
+
+# ------------------------------------------------------------------ round 2: row slabs, exception set, configs[0]
+@pytest.mark.parametrize("shape,rows", [((2, 16, 24), (4, 12)), ((1, 7, 9), (2, 5)), ((2, 10, 6), (0, 5)), ((2, 10, 6), (5, 10)),
+                                        ((1, 33, 64), (32, 33)), ((3, 12, 20), (0, 12))])
+@pytest.mark.parametrize("mask_kind", [None, "bool", "f32"])
+def test_layer_rows_equal_the_same_rows_of_the_whole_image(ops, dev, shape, rows, mask_kind):
+    """curl_layer_fwd_slab_f32 (split-pixels layout): rows [r0, r1) of the full tensors, in place, bit-identical to
+    those rows of the whole-image call; nothing outside the slab is written.  Vector and scalar kernels."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+    mask = None
+    if mask_kind == "bool":
+        mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+    elif mask_kind == "f32":
+        mask = torch.rand(B, 1, H, W, generator=g).to(dev)
+    full, reg = ops.curl_layer_forward(img, mask, L, R, Hk)
+    out = torch.full_like(img, -7.0)
+    got, reg2 = ops.curl_layer_forward_rows(img, mask, L, R, Hk, rows, out)
+    r0, r1 = rows
+    assert got is out and torch.equal(out[:, :, r0:r1], full[:, :, r0:r1]) and torch.equal(reg2, reg)
+    untouched = torch.ones(H, dtype=torch.bool)
+    untouched[r0:r1] = False
+    assert (out[:, :, untouched.to(dev)] == -7.0).all()
+    # in place on the image itself
+    work = img.clone()
+    ops.curl_layer_forward_rows(work, mask, L, R, Hk, rows, work)
+    assert torch.equal(work[:, :, r0:r1], full[:, :, r0:r1]) and torch.equal(work[:, :, untouched.to(dev)], img[:, :, untouched.to(dev)])
+
+
+@pytest.mark.parametrize("nc", [126, 35])
+@pytest.mark.parametrize("shape,rows", [((2, 30, 52), (7, 19)), ((1, 9, 7), (3, 9)), ((2, 16, 1500), (8, 16))])
+def test_trispace_rows_keep_the_full_image_coordinates(ops, dev, nc, shape, rows):
+    """The polynomial's y = row / H must be the FULL image's (model.py:487-497): the slab entry equals the rows of the
+    whole-image call bit for bit, while slicing the tensor first (what apply_row_slab did in round 1) does not."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(nc + H)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    coeffs = (torch.randn(B, 3, 3, nc, generator=g) * 0.2).to(dev)
+    full = ops.trispace_forward(img, coeffs)
+    out = torch.full_like(img, -7.0)
+    ops.trispace_forward_rows(img, coeffs, rows, out)
+    r0, r1 = rows
+    assert torch.equal(out[:, :, r0:r1], full[:, :, r0:r1])
+    assert (out[:, :, :r0] == -7.0).all() and (out[:, :, r1:] == -7.0).all()
+    if nc == 126 and r0 > 0:
+        sliced = ops.trispace_forward(img[:, :, r0:r1].contiguous(), coeffs)
+        assert not torch.equal(sliced, full[:, :, r0:r1])  # the renumbered rows of the round-1 route
+    from curl_amd import shard
+    both = torch.zeros_like(img)
+    for rank in range(3):  # three "ranks" tile the image
+        o, (a, b) = shard.apply_row_slab_trispace(img, coeffs, rank, 3)
+        both[:, :, a:b] = o[:, :, a:b]
+    assert torch.equal(both, full)
+
+
+def test_row_slab_arguments_are_checked(ops, dev):
+    img = torch.rand(1, 3, 8, 8, device=dev)
+    L, R, Hk = (torch.zeros(1, n, device=dev) for n in (48, 48, 64))
+    out = torch.empty_like(img)
+    for rows in ((0, 0), (-1, 4), (4, 9), (5, 3)):
+        with pytest.raises(ValueError):
+            ops.curl_layer_forward_rows(img, None, L, R, Hk, rows, out)
+    with pytest.raises(ValueError):
+        ops.curl_layer_forward_rows(img, None, L, R, Hk, (0, 4), torch.empty(1, 3, 4, 8, device=dev))
+    from curl_amd import _lib
+    lib = _lib.load()
+    assert lib.curl_layer_fwd_slab_f32(img.data_ptr(), 0, 0, L.data_ptr(), R.data_ptr(), Hk.data_ptr(), out.data_ptr(), 0,
+                                       0, 0, 1, 8, 8, 6, 4, 16, 16, 16, 0, 0) == -2  # rows leave the image
+    assert b"slab" in lib.curl_last_error()
+
+
+def _input_sensitivity(O, img, mf, L, R, Hk, r64, h=1e-6):
+    """max over the three input channels and both signs of |d out / d in| per pixel, by finite differences of the
+    reference chain evaluated in float64: how much the chain amplifies a rounding-sized perturbation at this pixel."""
+    S = torch.zeros(r64.shape[0], r64.shape[2], r64.shape[3], dtype=torch.float64)
+    for k in range(3):
+        for sgn in (1.0, -1.0):
+            p = img.double().clone()
+            p[:, k] += sgn * h
+            o, _ = O.curl_layer(p, mf.double(), L.double(), R.double(), Hk.double())
+            S = torch.maximum(S, (o - r64).abs().amax(1) / h)
+    return S
+
+
+def test_fullsize_exception_set_is_pinned_by_conditioning(ops, big):
+    """WHICH pixels may differ from the reference by more than 1e-5, and by how much.
+
+    The chain amplifies rounding noise where it is ill-conditioned (out-of-gamut Lab->RGB values met unclamped by
+    the R curve, gamma slope 12.92 at black, hue ~ 1/(max-min)): there the reference's own float32 result moves by
+    more than 1e-5 when torch merely vectorises differently (a pixel evaluated alone vs inside the frame), so its
+    realised float32 noise at a pixel is not a stable yardstick.  The stable one is the chain's input sensitivity
+    S = max |d out / d in| of the float64 evaluation.  Pinned here, per pixel:
+        |HIP - ref32| <= max(1e-5, 2e-6 * S)      and      |HIP - ref64| <= max(1e-5, 2e-6 * S)
+    i.e. a pixel may exceed 1e-5 only if S > 5 (2 % of frame 0, none of frame 1), and then by no more than 2e-6 per
+    unit of amplification -- the bound the reference's float32 evaluation itself needs (measured 1.8e-6 * S).  On the
+    well-conditioned frame 1 the strict 1e-5 holds on every pixel."""
+    import curl_oracle as O
+    dev = big[0].device
+    for b, strict in ((1, True), (0, False)):
+        img, mask, L, R, Hk = (t[b:b + 1].cpu() for t in big)
+        mf = mask.float()
+        ref, _ = O.curl_layer(img, mf, L, R, Hk)
+        r64, _ = O.curl_layer(img.double(), mf.double(), L.double(), R.double(), Hk.double())
+        out, _ = ops.curl_layer_forward(img.to(dev), mask.to(dev), L.to(dev), R.to(dev), Hk.to(dev))
+        out = out.cpu().double()
+        d = (out - ref.double()).abs().amax(1)
+        ours = (out - r64).abs().amax(1)
+        if strict:
+            assert float(d.max()) <= 1e-5 and float(ours.max()) <= 1e-5
+            continue
+        S = _input_sensitivity(O, img, mf, L, R, Hk, r64)
+        bound = torch.clamp(2e-6 * S, min=1e-5)
+        assert int((d > bound).sum()) == 0, (int((d > bound).sum()), float((d / bound).max()))
+        assert int((ours > bound).sum()) == 0, (int((ours > bound).sum()), float((ours / bound).max()))
+        over = d > 1e-5
+        assert 0 < int(over.sum()) < 2e-3 * over.numel()      # the set exists on this frame, and is small
+        assert float(S[over].min()) > 5.0                       # ... and consists of ill-conditioned pixels only
+        assert float(((S > 5.0) & (mask[:, 0].cpu())).double().mean()) < 0.08   # which are few
+        # the reference's own float32 evaluation needs the same allowance on this frame
+        noise = (ref.double() - r64).abs().amax(1)
+        assert float((noise > 1e-5).double().mean()) > 0.5 * float(over.double().mean())
+
+
+def test_config1_real_image_pixels_on_the_hip_path(ops, dev, golden):
+    """BASELINE configs[0]: pixels of the reference's example image (adobe5k_dpe/curl_example_test_input, 16x16 corner
+    of the 256x256 centre crop) with the golden knots, HIP layer vs the reference-generated output; and the byte
+    output through the fused uint8 entry point."""
+    c = golden("config1")
+    x = T(c["in_corner"], dev)[None]
+    L, R, Hk = T(c["L"], dev), T(c["R"], dev), T(c["H"], dev)
+    out, reg = ops.curl_layer_forward(x, torch.ones(1, 1, 16, 16, dtype=torch.bool, device=dev), L, R, Hk)
+    assert max_err(N(out)[0], c["out_corner"]) <= 1e-5
+    np.testing.assert_allclose(N(reg), c["reg"], rtol=2e-6)
+    u8 = ops.f32chw_to_u8hwc(out)[0]
+    assert (N(u8).astype(int) - c["out_u8_corner"].astype(int)).__abs__().max() <= 1
+    out_none, _ = ops.curl_layer_forward(x, None, L, R, Hk)
+    assert torch.equal(out_none, out)

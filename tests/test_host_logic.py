@@ -268,3 +268,33 @@ def test_out_argument_is_validated():
             ops._check_out(bad, img)
     with pytest.raises(TypeError):
         ops._check_out([1, 2], img)
+
+
+class _RandProbe(torch.utils.data.Dataset):
+    """Reports the augmentation draws a data.Dataset makes inside DataLoader workers."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return torch.tensor([self.ds._rand(), self.ds._rand()])
+
+
+def test_augmentation_streams_differ_across_workers_and_epochs():
+    """a seeded private generator copied into every DataLoader worker replayed ONE augmentation stream in
+    all workers and all epochs; the reference's global-RNG draws differ per worker and per epoch."""
+    from curl_amd import data
+    ds = data.Dataset({}, is_train=True, seed=123)
+    loader = torch.utils.data.DataLoader(_RandProbe(ds), batch_size=1, shuffle=False, num_workers=2)
+    epochs = [torch.cat([b for b in loader]) for _ in range(2)]  # items 0,2 -> worker 0; items 1,3 -> worker 1
+    e0, e1 = epochs
+    assert not torch.equal(e0[0], e0[1])      # two workers, first draw each: different streams
+    assert not torch.equal(e0, e1)            # next epoch: different draws
+    assert len({float(v) for v in torch.cat([e0, e1]).flatten()}) == 16
+    # without workers the one generator simply advances (and is reproducible from the seed)
+    a = data.Dataset({}, is_train=True, seed=5)
+    b = data.Dataset({}, is_train=True, seed=5)
+    assert [a._rand() for _ in range(3)] == [b._rand() for _ in range(3)]

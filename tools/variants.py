@@ -16,28 +16,31 @@ from curl_amd import build as B  # noqa: E402
 OUT_DIR = os.path.join(ROOT, "curl_amd", "lib", "variants")
 
 # name -> extra compiler switches
+R1 = ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=0"]  # the round-1 code: packed helpers, every wave at one priority
+
 VARIANTS = {
-    "base": [],
+    "base": [],  # = the product library's switches
     # in-kernel s_memtime / s_memrealtime stamps per wave (tools/stamp.py)
     "stamp": ["-DCURL_DIAG_STAMP"],
+    "r1_stamp": R1 + ["-DCURL_DIAG_STAMP"],
     # loads issued, arithmetic on synthetic values: separates "waiting for data" from "sharing the chip with traffic"
     "nodep": ["-DCURL_DIAG_NO_DEP"],
     # scheduling fences around the transcendental runs removed
     "nofence": ["-DCURL_NO_FENCE"],
-    # dual-issue experiments (curl_math.h): issue priority by phase, constants / coefficients in VGPRs
-    "prio1": ["-DCURL_EXP_PRIO=1"],
-    "prio3": ["-DCURL_EXP_PRIO=3"],
-    "vconst": ["-DCURL_EXP_VCONST"],
-    "vconst_prio1": ["-DCURL_EXP_VCONST", "-DCURL_EXP_PRIO=1"],
-    # the other way round: the UNPAIRABLE runs (transcendental, packed) at raised priority
-    "ps_t1": ["-DCURL_PRIO_TRANS=1"],
-    "ps_tp1": ["-DCURL_PRIO_TRANS=1", "-DCURL_PRIO_PK=1"],
-    "ps_t2p1": ["-DCURL_PRIO_TRANS=2", "-DCURL_PRIO_PK=1"],
-    "ps_tp3": ["-DCURL_PRIO_TRANS=3", "-DCURL_PRIO_PK=3"],
-    "ps_p1": ["-DCURL_PRIO_PK=1"],
-    # packed-FP32 helpers as scalar loops (plain instructions can pair, packed ones cannot)
-    "nopk": ["-DCURL_NO_PK"],
-    "nopk_t1": ["-DCURL_NO_PK", "-DCURL_PRIO_TRANS=1"],
+    # ---- dual-issue record (curl_math.h) ----
+    "r1": R1,
+    # plain code at RAISED priority (the first guess; makes it worse)
+    "r1_fast1": ["-DCURL_USE_PK", "-DCURL_EXP_PRIO=1"],
+    # constants / coefficients of the scalar FMAs in VGPRs (an SGPR-operand instruction pairs with a plain one anyway)
+    "r1_vconst": R1 + ["-DCURL_EXP_VCONST"],
+    # the unpairable runs at raised priority: transcendental only, packed only, both
+    "pk_t1": ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=1"],
+    "pk_p1": ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=0", "-DCURL_PRIO_PK=1"],
+    "pk_tp1": ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=1", "-DCURL_PRIO_PK=1"],
+    "pk_tp3": ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=3", "-DCURL_PRIO_PK=3"],
+    # scalar helpers: without priorities, with transcendental runs at 1 (= base), at 3
+    "nopk_t0": ["-DCURL_PRIO_TRANS=0"],
+    "nopk_t3": ["-DCURL_PRIO_TRANS=3"],
 }
 
 
