@@ -4,7 +4,7 @@
 # pass A: kernel trace + stats; pass B: SQ counters; pass C: FETCH_SIZE; pass D: WRITE_SIZE
 # (counters in their own runs, no sys/hip traces -- see the task notes on this pool)
 set -u
-W=${1:-layer}; TAG=${2:-r01}
+W=${1:-layer}; TAG=${2:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_${TAG}_${W}
 mkdir -p $OUT
