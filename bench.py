@@ -184,9 +184,12 @@ def accuracy_vs_oracle(ops, device):
         "sample": "1 x 1500x1000 frame, knots N(0,0.1), bool disk mask, vs oracle (fp32 reference arithmetic)",
         "max_abs_err": float(d.max()),
         "frac_px_over_1e-5": float(over.double().mean()),
-        "ref_self_noise_max": float(noise.max()),
+        # the reference is discontinuous on the hue seam (g == b with r maximal: hue 0 <-> 1 in front of a non-periodic
+        # hue curve): there its float32 and float64 evaluations land on different sides -- counted, then set aside
+        "px_where_ref32_and_ref64_take_different_hue_branches": int(((noise > 1e-3).any(1)).sum()),
+        "ref_self_noise_max": float(noise[noise <= 1e-3].max()),
         "ref_self_noise_frac_over_1e-5": float((noise > 1e-5).double().mean()),
-        "ours_vs_f64_max": float(ours.max()),
+        "ours_vs_f64_max": float(ours[noise <= 1e-3].max()),
         "ours_vs_f64_frac_over_1e-5": float((ours > 1e-5).double().mean()),
         "frac_of_over_1e-5_px_where_ref_noise_over_2.5e-6": (float((noise[over] > 2.5e-6).double().mean())
                                                               if bool(over.any()) else None),

@@ -232,6 +232,17 @@ struct PxN {
 #define CURL_TRANS_BEGIN() ((void)0)
 #define CURL_TRANS_END() ((void)0)
 #endif
+// the polynomial model's packed Horner code (curl_math_poly.h): CURL_PRIO_POLY, default = plain code's level
+#if !defined(CURL_PRIO_POLY)
+#define CURL_PRIO_POLY CURL_PRIO_FAST
+#endif
+#if CURL_PRIO_POLY != CURL_PRIO_FAST
+#define CURL_POLY_BEGIN() CURL_SETPRIO(CURL_PRIO_POLY)
+#define CURL_POLY_END() CURL_SETPRIO(CURL_PRIO_FAST)
+#else
+#define CURL_POLY_BEGIN() ((void)0)
+#define CURL_POLY_END() ((void)0)
+#endif
 //   CURL_EXP_VCONST : experiment build, constants and curve coefficients of the scalar FMAs in VGPRs instead of SGPRs.
 CURL_HD float vconst(float k) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(CURL_EXP_VCONST)

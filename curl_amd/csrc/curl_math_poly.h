@@ -100,6 +100,7 @@ CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float*
         v[q][k].x = vars[k][2 * q];
         v[q][k].y = vars[k][2 * q + 1];
       }
+    CURL_POLY_BEGIN();  // packed code: never pairs with another wave's instruction (curl_math.h, issue priority)
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
       CURL_FENCE();
@@ -110,6 +111,7 @@ CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float*
         out[o][2 * q + 1] = r[q].y;
       }
     }
+    CURL_POLY_END();
     CURL_FENCE();
   }
   if (N & 1) {
@@ -139,6 +141,7 @@ template <int M>
 CURL_HD void sigmoid_run(float (&x)[M]) {
   scale_run(x, x, (float)(-1.4426950408889634));  // -log2(e)
   CURL_FENCE();
+  CURL_TRANS_BEGIN();
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = hw_exp2(x[i]);
   CURL_FENCE();
@@ -147,6 +150,7 @@ CURL_HD void sigmoid_run(float (&x)[M]) {
   CURL_FENCE();
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = hw_rcp(x[i]);  // 1 ulp: 6e-8 of a value in (0,1)
+  CURL_TRANS_END();
   CURL_FENCE();
 }
 

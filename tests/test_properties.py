@@ -1,0 +1,110 @@
+"""Property tests (SURVEY.md section 4 iii): hypothesis searches the edge values of the per-pixel arithmetic -- channel
+ties, 8-bit grid values, threshold neighbours, out-of-range inputs -- and shrinks a failure to one pixel.  They run the
+kernels' arithmetic through the host twin of curl_math.h (tests/twin/), i.e. the same header the HIP kernels compile,
+against the oracle; the GPU suite then checks the compiled kernels against the same oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import curl_oracle as O
+
+F32 = np.float32
+THRESHOLDS = [0.04045, 0.0031308, (6 / 29) ** 3, 6 / 29, 0.0, 1.0, 1e-9, 1e-4]
+
+
+def _near(v):
+    v = F32(v)
+    return [float(v), float(np.nextafter(v, F32(2))), float(np.nextafter(v, F32(-2)))]
+
+
+channel = st.one_of(
+    st.floats(-0.5, 1.5, width=32),
+    st.integers(0, 255).map(lambda k: float(F32(k) / F32(255))),
+    st.sampled_from([x for t in THRESHOLDS for x in _near(t)]),
+)
+unit_channel = st.one_of(st.floats(0.0, 1.0, width=32), st.integers(0, 255).map(lambda k: float(F32(k) / F32(255))),
+                         st.sampled_from([x for t in THRESHOLDS for x in _near(t) if 0.0 <= x <= 1.0]))
+
+
+@st.composite
+def pixels(draw, elem=channel, max_px=16):
+    n = draw(st.integers(1, max_px))
+    px = []
+    for _ in range(n):
+        a, b, c = draw(elem), draw(elem), draw(elem)
+        tie = draw(st.integers(0, 5))  # ties between channels are where the hue terms add (colors.py:221-224)
+        if tie == 1:
+            b = a
+        elif tie == 2:
+            c = b
+        elif tie == 3:
+            c = a
+        elif tie == 4:
+            b = c = a
+        px.append((a, b, c))
+    return np.asarray(px, dtype=np.float32).T.reshape(1, 3, 1, n).copy()
+
+
+COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@pytest.mark.parametrize("op,tol", [("rgb2lab", 2e-6), ("rgb2hsv", 1e-6), ("hsv2rgb", 1e-6)])
+@settings(max_examples=150, **COMMON)
+@given(x=pixels())
+def test_converter_matches_the_oracle_on_edge_values(twin, op, tol, x):
+    ref = getattr(O, op)(torch.from_numpy(x)).numpy()
+    got = twin.convert(op, x)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all()
+    assert float(np.abs(got.astype(np.float64) - ref).max()) <= tol * scale
+
+
+@settings(max_examples=150, **COMMON)
+@given(x=pixels(elem=st.one_of(st.floats(-0.25, 1.25, width=32), st.sampled_from([x for t in (6 / 29, 0.0, 1.0) for x in _near(t)]))))
+def test_lab2rgb_matches_the_oracle_on_edge_values(twin, x):
+    """Out-of-gamut Lab values included (the fused layer feeds exactly those: colors.py:121-123 does not clamp)."""
+    t = torch.from_numpy(x)
+    ref = O.lab2rgb(t).numpy()
+    got = twin.convert("lab2rgb", x)
+    # Out of gamut the conversion cancels terms of size |XYZ| ~ 3 and multiplies what is left by 12.92 (linear branch):
+    # rounding-sized differences in fx, fy, fz are amplified by the map's own sensitivity S = max |d out / d in|
+    # (float64, finite differences).  In gamut S is ~1-10 and the plain 2e-6 holds.
+    r64 = O.lab2rgb(t.double())
+    S = torch.zeros(1, 1, t.shape[3], dtype=torch.float64)
+    for k in range(3):
+        for sgn in (1e-6, -1e-6):
+            p = t.double().clone()
+            p[:, k] += sgn
+            S = torch.maximum(S, (O.lab2rgb(p) - r64).abs().amax(1) / 1e-6)
+    bound = torch.clamp(2e-7 * S, min=2e-6 * max(1.0, float(np.abs(ref).max())))
+    d = torch.from_numpy(np.abs(got.astype(np.float64) - ref)).amax(1)
+    assert bool((d <= bound).all()), (float(d.max()), float(S.max()))
+
+
+@settings(max_examples=60, **COMMON)
+@given(x=pixels(elem=unit_channel, max_px=8), seed=st.integers(0, 2 ** 16), binary=st.booleans())
+def test_fused_layer_error_is_bounded_by_the_chain_conditioning(twin, x, seed, binary):
+    """|kernel arithmetic - reference (float32)| <= max(1e-5, 2e-6 * S), S = input sensitivity of the reference chain in
+    float64 (tests/test_gpu_parity.py::test_fullsize_exception_set_is_pinned_by_conditioning states the same on the GPU).
+    Pixels ON a discontinuity of the reference (exact channel ties in front of the hue computation flip branches under
+    any rounding) are recognised by S itself becoming huge."""
+    g = torch.Generator().manual_seed(seed)
+    L, R, H = (torch.randn(1, n, generator=g) * 0.1 for n in (48, 48, 64))
+    img = torch.from_numpy(x)
+    n = img.shape[3]
+    mask = torch.ones(1, 1, 1, n)
+    ref, _ = O.curl_layer(img, mask, L, R, H)
+    r64, _ = O.curl_layer(img.double(), mask.double(), L.double(), R.double(), H.double())
+    S = torch.zeros(1, 1, n, dtype=torch.float64)
+    for k in range(3):
+        for sgn in (1e-6, -1e-6):
+            p = img.double().clone()
+            p[:, k] += sgn
+            o, _ = O.curl_layer(p, mask.double(), L.double(), R.double(), H.double())
+            S = torch.maximum(S, (o - r64).abs().amax(1) / 1e-6)
+    got, _ = twin.layer(1, x, mask.numpy(), L.numpy(), R.numpy(), H.numpy(), binary=binary)
+    d = (torch.from_numpy(got).double() - ref.double()).abs().amax(1)
+    bound = torch.clamp(2e-6 * S, min=1e-5)
+    assert bool((d <= bound).all()), (float(d.max()), float(S.max()))

@@ -69,7 +69,7 @@ def main():
     for _ in range(150):  # clock settle
         run(libs["A"], 0)
     torch.cuda.synchronize()
-    for r in range(11):
+    for r in range(int(os.environ.get('ROUNDS', 11))):
         for v in (variants if r % 2 == 0 else variants[::-1]):
             for _ in range(20):
                 run(libs[v[0]], v[1] | extra[v[0]])

@@ -29,6 +29,7 @@ def main():
     mask = torch.ones(B, 1, H, W, dtype=torch.uint8, device=dev)
     L, R, Hk = (torch.randn(B, k, device=dev) * 0.1 for k in (48, 48, 64))
     reg = torch.empty(B, device=dev)
+    poly = torch.randn(B, 3, 3, 126, device=dev) * 0.2
     nb = lib.curl_workspace_bytes(B, 160)
     ws = torch.empty(nb // 4, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -38,6 +39,8 @@ def main():
         if what == "layer":
             rc = lib.curl_layer_fwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
                                         out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nb, B, H, W, 16, 16, 16, flags, stream)
+        elif what == "trispace":
+            rc = lib.curl_trispace_fwd_f32(img.data_ptr(), poly.data_ptr(), out.data_ptr(), B, H, W, 126, flags, stream)
         else:
             rc = lib.curl_lab_stage_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                         ws.data_ptr(), nb, B, H, W, 16, flags, stream)

@@ -41,6 +41,10 @@ VARIANTS = {
     # scalar helpers: without priorities, with transcendental runs at 1 (= base), at 3
     "nopk_t0": ["-DCURL_PRIO_TRANS=0"],
     "nopk_t3": ["-DCURL_PRIO_TRANS=3"],
+    # polynomial model: its packed Horner code at raised priority too / the converters' helpers packed again
+    "poly1": ["-DCURL_PRIO_POLY=1"],
+    "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
+    "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
 }
 
 
