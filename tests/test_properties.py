@@ -70,7 +70,8 @@ def test_lab2rgb_matches_the_oracle_on_edge_values(twin, x):
     got = twin.convert("lab2rgb", x)
     # Out of gamut the conversion cancels terms of size |XYZ| ~ 3 and multiplies what is left by 12.92 (linear branch):
     # rounding-sized differences in fx, fy, fz are amplified by the map's own sensitivity S = max |d out / d in|
-    # (float64, finite differences).  In gamut S is ~1-10 and the plain 2e-6 holds.
+    # (float64, finite differences).  In gamut S is ~1-10 and the plain 2e-6 holds.  Measured over 2e5 random Lab
+    # triples in [-0.25, 1.25]^3: |twin - ref32| <= 6.0e-7 * S, |twin - f64| <= 4.6e-7 * S, |ref32 - f64| <= 4.6e-7 * S.
     r64 = O.lab2rgb(t.double())
     S = torch.zeros(1, 1, t.shape[3], dtype=torch.float64)
     for k in range(3):
@@ -78,7 +79,7 @@ def test_lab2rgb_matches_the_oracle_on_edge_values(twin, x):
             p = t.double().clone()
             p[:, k] += sgn
             S = torch.maximum(S, (O.lab2rgb(p) - r64).abs().amax(1) / 1e-6)
-    bound = torch.clamp(2e-7 * S, min=2e-6 * max(1.0, float(np.abs(ref).max())))
+    bound = torch.clamp(8e-7 * S, min=2e-6 * max(1.0, float(np.abs(ref).max())))
     d = torch.from_numpy(np.abs(got.astype(np.float64) - ref)).amax(1)
     assert bool((d <= bound).all()), (float(d.max()), float(S.max()))
 
