@@ -16,6 +16,7 @@ F_EXACT_ORDER = 0x1
 F_PWL = 0x2
 F_RESIDUAL_ONLY = 0x4
 F_TUNE_UNROLL_SHIFT = 8
+F_TUNE_BLOCK_SHIFT = 11
 F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
 MAX_KNOTS = 256

@@ -62,6 +62,8 @@ enum {
 /* tuning bits (0 = library default; used by the bench sweep, never change results) */
 #define CURL_F_TUNE_UNROLL_SHIFT 8 /* bits 8..10: float4 groups per thread, 0 = default */
 #define CURL_F_TUNE_UNROLL_MASK 0x700u
+#define CURL_F_TUNE_BLOCK_SHIFT 11 /* bits 11..12: threads per workgroup of the streaming kernels, 0 = 256, 1 = 128, 2 = 64 */
+#define CURL_F_TUNE_BLOCK_MASK 0x1800u
 #define CURL_F_TUNE_NO_NT 0x8000u     /* plain loads/stores instead of the default non-temporal ones */
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */
