@@ -29,12 +29,58 @@ template <>
 struct PolyCoef<float> {
   static CURL_HD float seq(const float* c, int q) { return c[q]; }
   static CURL_HD float ref(float x) { return x; }
+  // the first fma of a Horner chain: its initial value is coefficient QA itself (consumption-order table)
+  template <int QA, int QB>
+  static CURL_HD float fma_cc(const float* c, float v) { return fmaf(c[QA], v, c[QB]); }
+  template <int QA>
+  static CURL_HD float fmav_c(const float* c, float v, float t) { return fmaf(c[QA], v, t); }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <>
 struct PolyCoef<curl_f2> {
   static CURL_HD curl_f2 seq(const float* c, int q) { return splat2(c[q]); }
   static CURL_HD curl_f2 ref(float x) { return splat2(x); }
+  // Coefficient q lives in half (q & 1) of the aligned 8-byte pair at c + (q & ~1).  v_pk_fma_f32 can take either
+  // half of a source pair for BOTH result halves (op_sel / op_sel_hi); hipcc uses that for an addend but builds a
+  // {c, c} pair with a v_mov when the coefficient is the multiplicand -- the chain's first fma, 160 per 4 pixels.
+  // Written out here, the select costs nothing.
+  // (read as half of the aligned 16-byte group, so that the reads stay ds_read_b128: polynomials start on 16-byte
+  // boundaries of the LDS table, kSeqStride)
+  static __device__ __forceinline__ curl_f2 pair(const float* c, int q) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 g = *reinterpret_cast<const f4*>(c + (q & ~3));
+    return (q & 2) ? __builtin_shufflevector(g, g, 2, 3) : __builtin_shufflevector(g, g, 0, 1);
+  }
+  template <int QA, int QB>
+  static __device__ __forceinline__ curl_f2 fma_cc(const float* c, curl_f2 v) {
+#if defined(CURL_POLY_SPLAT_FIRST)  // experiment build: the round-1 form (broadcast built by the compiler)
+    return poly_fmav(splat2(c[QA]), v, splat2(c[QB]));
+#endif
+    const curl_f2 a = pair(c, QA), b = pair(c, QB);
+    curl_f2 r;
+    if constexpr ((QA & 1) == 0 && (QB & 1) == 0)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(v), "v"(b));
+    else if constexpr ((QA & 1) == 1 && (QB & 1) == 0)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(v), "v"(b));
+    else if constexpr ((QA & 1) == 0 && (QB & 1) == 1)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(v), "v"(b));
+    else
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(v), "v"(b));
+    return r;
+  }
+  template <int QA>
+  static __device__ __forceinline__ curl_f2 fmav_c(const float* c, curl_f2 v, curl_f2 t) {
+#if defined(CURL_POLY_SPLAT_FIRST)
+    return poly_fmav(splat2(c[QA]), v, t);
+#endif
+    const curl_f2 a = pair(c, QA);
+    curl_f2 r;
+    if constexpr ((QA & 1) == 0)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(v), "v"(t));
+    else
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(v), "v"(t));
+    return r;
+  }
 };
 #endif
 #define CURL_POLY_SPLAT(c) (c)

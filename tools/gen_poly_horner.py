@@ -77,24 +77,63 @@ def gen(degree, nvars):
     FENCE_EVERY = 12
     out_lines = []
     import re
-    used = 0        # coefficients consumed so far (the q of CURL_POLY_C(q) is sequential by construction)
+    # A chain's initial value is a coefficient broadcast to every pixel (CURL_POLY_SPLAT) that the chain's FIRST fma
+    # multiplies.  Materialising the broadcast costs a v_mov per odd-positioned coefficient on gfx950 (hipcc folds the
+    # half-select into op_sel for an addend, not for a multiplicand): 160 per 4 pixels.  The generator therefore hands
+    # the coefficient INDEX to that first fma (CURL_POLY_FMA_CC / CURL_POLY_FMAV_C: packed type = one v_pk_fma_f32 with
+    # op_sel picking the half of the 8-byte pair the coefficient sits in; float = fmaf) and never forms the splat.
+    splat = {}      # temp name -> consumption position of the coefficient it would have been a splat of
+    read = set()    # consumption positions read so far
     last_fence = 0
+
+    def cidx(expr):
+        m = re.fullmatch(r"CURL_POLY_C\((\d+)\)", expr)
+        return int(m.group(1)) if m else None
+
     for l in lines:
-        used += len(re.findall(r"CURL_POLY_C\(", l))
         m = re.match(r"  F (t\d+) = (.*);", l)
         if m:
             name, rhs = m.group(1), m.group(2)
-            rhs_p = re.sub(r"\b(t\d+)\b", r"\1[p]", rhs)
-            out_lines.append(f"  F {name}[NP];")
-            out_lines.append(f"  CURL_POLY_EACH {name}[p] = {rhs_p};")
+            out_lines.append(f"  F {name}[NP];  // DECL")
+            ms = re.fullmatch(r"CURL_POLY_SPLAT\((CURL_POLY_C\(\d+\))\)", rhs)
+            if ms:
+                splat[name] = cidx(ms.group(1))
+            elif rhs in splat:
+                splat[name] = splat[rhs]
+            else:
+                assert re.fullmatch(r"t\d+", rhs), rhs
+                out_lines.append(f"  CURL_POLY_EACH {name}[p] = {rhs}[p];")
         else:
-            m = re.match(r"  (t\d+) = (.*);", l)
-            name, rhs = m.group(1), m.group(2)
-            rhs_p = re.sub(r"\b(t\d+)\b", r"\1[p]", rhs).replace("v[", "v[p][")
-            out_lines.append(f"  CURL_POLY_EACH {name}[p] = {rhs_p};")
-        if used % 4 == 0 and used - last_fence >= FENCE_EVERY:
+            m = re.match(r"  (t\d+) = (CURL_POLY_FMAV?)\((t\d+), (v\[\d+\]), (.*)\);", l)
+            name, kind, a, var, add = m.groups()
+            assert name == a
+            var = var.replace("v[", "v[p][")
+            qb = cidx(add)
+            if qb is not None:
+                read.add(qb)
+            else:
+                assert add not in splat, l
+            if a in splat:
+                qa = splat.pop(a)
+                read.add(qa)
+                if qb is not None:
+                    out_lines.append(f"  CURL_POLY_EACH {name}[p] = CURL_POLY_FMA_CC({qa}, {var}, {qb});")
+                else:
+                    out_lines.append(f"  CURL_POLY_EACH {name}[p] = CURL_POLY_FMAV_C({qa}, {var}, {add}[p]);")
+            elif qb is not None:
+                out_lines.append(f"  CURL_POLY_EACH {name}[p] = CURL_POLY_FMA({name}[p], {var}, CURL_POLY_C({qb}));")
+            else:
+                out_lines.append(f"  CURL_POLY_EACH {name}[p] = CURL_POLY_FMAV({name}[p], {var}, {add}[p]);")
+        # a fence only where the positions read so far are exactly a 16-byte-aligned prefix of the table
+        n = len(read)
+        if read == set(range(n)) and n % 4 == 0 and n - last_fence >= FENCE_EVERY:
             out_lines.append("  CURL_FENCE();")
-            last_fence = used
+            last_fence = n
+    assert result not in splat, "degree-0 polynomial not supported here"
+    assert read == set(range(len(table))), (sorted(set(range(len(table))) - read))
+    assigned = set(re.findall(r"CURL_POLY_EACH (t\d+)\[p\] =", "\n".join(out_lines)))
+    out_lines = [l.replace("  // DECL", "") for l in out_lines
+                 if not l.endswith("// DECL") or re.match(r"  F (t\d+)\[", l).group(1) in assigned]
     body = "\n".join(out_lines)
     tab = ", ".join(str(i) for i in order)
     return table, f"""// degree {degree}, {nvars} variables: {len(table)} coefficients, {n_fma} FMAs per chain
@@ -107,10 +146,14 @@ constexpr unsigned short kPolyOrder_d{degree}_v{nvars}[{len(table)}] = {{{tab}}}
 template <class F, bool SEQ, int NP>
 CURL_HD void poly_d{degree}_v{nvars}(F (&out)[NP], const F (&v)[NP][{nvars}], const float* c) {{
 #define CURL_POLY_C(q) (SEQ ? PolyCoef<F>::seq(c, q) : PolyCoef<F>::ref(c[kPolyOrder_d{degree}_v{nvars}[q]]))
+#define CURL_POLY_FMA_CC(qa, v, qb) (SEQ ? PolyCoef<F>::template fma_cc<qa, qb>(c, v) : CURL_POLY_FMA(CURL_POLY_C(qa), v, CURL_POLY_C(qb)))
+#define CURL_POLY_FMAV_C(qa, v, t) (SEQ ? PolyCoef<F>::template fmav_c<qa>(c, v, t) : CURL_POLY_FMAV(CURL_POLY_C(qa), v, t))
 #define CURL_POLY_EACH _Pragma("unroll") for (int p = 0; p < NP; ++p)
 {body}
   CURL_POLY_EACH out[p] = {result}[p];
 #undef CURL_POLY_EACH
+#undef CURL_POLY_FMAV_C
+#undef CURL_POLY_FMA_CC
 #undef CURL_POLY_C
 }}
 """
@@ -160,7 +203,9 @@ def main():
     parts = ["// GENERATED by tools/gen_poly_horner.py -- do not edit.\n"
              "// Multivariate Horner evaluators in the coefficient order of the reference's generate_powers\n"
              "// (model.py:222-246).  F = float (host twin) or a packed 2-pixel vector (gfx950: v_pk_fma_f32).\n"
-             "// CURL_POLY_C(q): coefficient q as an F; CURL_POLY_SPLAT(c): identity; CURL_POLY_FMA / FMAV(a, v, q): a*v + q.\n"]
+             "// CURL_POLY_C(q): coefficient q as an F; CURL_POLY_FMA / FMAV(a, v, q): a*v + q; CURL_POLY_FMA_CC(qa, v, qb) =\n"
+             "// coef[qa]*v + coef[qb] and CURL_POLY_FMAV_C(qa, v, t) = coef[qa]*v + t: the first fma of a chain, taking its\n"
+             "// initial coefficient by INDEX (see tools/gen_poly_horner.py).\n"]
     for degree, nvars in ((4, 5), (4, 3), (4, 4)):
         table, code = gen(degree, nvars)
         parts.append(code)

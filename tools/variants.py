@@ -42,6 +42,7 @@ VARIANTS = {
     "nopk_t0": ["-DCURL_PRIO_TRANS=0"],
     "nopk_t3": ["-DCURL_PRIO_TRANS=3"],
     # polynomial model: its packed Horner code at raised priority too / the converters' helpers packed again
+    "poly_splat": ["-DCURL_POLY_SPLAT_FIRST"],  # the chains' first fma from a compiler-built {c, c} pair (v_mov per odd c)
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
