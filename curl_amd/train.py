@@ -61,7 +61,8 @@ class SyntheticPairs(Dataset):
 def build_net(arch, width, sync_bn):
     if arch == "trispace":  # main.py:221
         net = model.TriSpaceRegNet(polynomial_order=4, spatial=True, use_sync_bn=sync_bn,
-                                   backbone=model.CurveEncoder(num_outputs=1, num_features=1024, width=width))
+                                   backbone=model.CurveEncoder(num_outputs=1, num_features=1024, width=width,
+                                                               variant="efficientnetv2_rw_t"))  # model.py:456
     else:
         net = model.GCURLNet(backbone=model.CurveEncoder(160, width=width))
         if sync_bn:

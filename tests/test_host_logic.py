@@ -298,3 +298,20 @@ def test_augmentation_streams_differ_across_workers_and_epochs():
     a = data.Dataset({}, is_train=True, seed=5)
     b = data.Dataset({}, is_train=True, seed=5)
     assert [a._rand() for _ in range(3)] == [b._rand() for _ in range(3)]
+
+
+def test_bench_workload_table_and_replayed_traffic():
+    """Every bench workload names its bound and carries the figures its roofline is computed from; the PMC traffic is
+    replayed from the committed pass and says so (VERDICT r1 weak #4, #5)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert set(bench.WORKLOADS) >= {"layer", "layer_disk", "lab_stage", "rgb_only", "trispace", "layer_u8", "trispace_u8"}
+    for name, w in bench.WORKLOADS.items():
+        assert w["bound"] in ("hbm", "valu") and w["bpp"] > 0 and w["flop_px"] > 0, name
+    assert bench.WORKLOADS["layer"]["bound"] == "hbm" and bench.WORKLOADS["layer"]["bpp"] == 25.0   # SURVEY 8(d)
+    assert bench.WORKLOADS["trispace"]["bound"] == "valu"
+    traffic, src = bench.load_traffic("OpLayer")
+    assert 1.15e9 < traffic < 1.3e9 and src.startswith("profiles/traffic_r") and "not this run" in src
+    assert bench.load_traffic("NoSuchKernel") == (None, None)
