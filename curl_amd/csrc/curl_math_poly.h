@@ -299,6 +299,20 @@ CURL_HD float collapse_coef(const float* c126, int pos, float y) {
   return acc;
 }
 
+// The same on the device, from one 16-byte row of the position-indexed table (kPolyFold_d4_v5: one load instead of a
+// chain of dependent 2-byte ones) and coefficients that already sit in LDS.  The valid entries are j = 0..4-deg(m);
+// starting the Horner chain from 0 makes the first step fma(0, y, c) = c, the value collapse_coef starts from.
+CURL_HD float collapse_coef_fold(const float* c126, int pos, float y) {
+  const PolyFoldRow e = kPolyFold_d4_v5[pos];
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 4; j >= 0; --j) {
+    const unsigned idx = e.j[j];
+    if (idx != 0xFFFFu) acc = fmaf(acc, y, c126[idx]);
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------- backward of the polynomial path
 // Training the fork's live model needs d loss / d coeffs only (the image is data).  Per pixel and space s:
 //   y_s = conv_s(sigmoid(P_s(vars_s))),  residual = sum_s 2 (y_s - 0.5),  out = clamp(img + residual)  [or residual]

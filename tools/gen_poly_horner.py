@@ -14,6 +14,7 @@ and reads coefficient t of the current output through the macro CURL_POLY_C(t).
 """
 import itertools
 import os
+import re
 import sys
 
 
@@ -197,6 +198,24 @@ def gen_collapse(degree, nvars):
             f"constexpr unsigned short kPolyCollapse_d{degree}_v{nvars}[{len(small)}][{degree + 1}] = {{\n  " + ",\n  ".join(rows) + "};\n").replace("\\n", "\n")
 
 
+def gen_fold(degree, nvars, order_small):
+    """The same collapse indexed by CONSUMPTION position of the (nvars-1)-variable Horner scheme, 8 entries of 16 bits
+    per position (16 bytes: one global_load_dwordx4 per folded coefficient on the device): entries 0..degree = reference
+    indices (nvars variables) of m * v_last^j, 0xFFFF = none; entries degree+1.. = 0xFFFF padding."""
+    full = {t: i for i, t in enumerate(powers(degree, nvars))}
+    small = powers(degree, nvars - 1)
+    rows = []
+    for pos in range(len(small)):
+        m = small[order_small[pos]]
+        ent = [str(full[m + (j,)]) if sum(m) + j <= degree else "0xFFFF" for j in range(degree + 1)]
+        ent += ["0xFFFF"] * (8 - len(ent))
+        rows.append("{" + ", ".join(ent) + "}")
+    return (f"// y-collapse by consumption position of the {nvars - 1}-variable scheme: kPolyFold[pos][j] = reference index of\n"
+            f"// (monomial consumed at pos) * v{nvars - 1}^j, 0xFFFF = none; 16 bytes per position\n"
+            f"struct alignas(16) PolyFoldRow {{ unsigned short j[8]; }};\n"
+            f"constexpr PolyFoldRow kPolyFold_d{degree}_v{nvars}[{len(small)}] = {{\n  " + ",\n  ".join("{" + r + "}" for r in rows) + "};\n").replace("\\n", "\n")
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "curl_amd", "csrc", "poly_horner.inc")
@@ -206,10 +225,13 @@ def main():
              "// CURL_POLY_C(q): coefficient q as an F; CURL_POLY_FMA / FMAV(a, v, q): a*v + q; CURL_POLY_FMA_CC(qa, v, qb) =\n"
              "// coef[qa]*v + coef[qb] and CURL_POLY_FMAV_C(qa, v, t) = coef[qa]*v + t: the first fma of a chain, taking its\n"
              "// initial coefficient by INDEX (see tools/gen_poly_horner.py).\n"]
+    orders = {}
     for degree, nvars in ((4, 5), (4, 3), (4, 4)):
         table, code = gen(degree, nvars)
         parts.append(code)
+        orders[nvars] = [int(x) for x in re.search(r"kPolyOrder_d4_v%d\[\d+\] = \{([^}]*)\}" % nvars, code).group(1).split(",")]
     parts.append(gen_collapse(4, 5))
+    parts.append(gen_fold(4, 5, orders[4]))
     parts.append(gen_monomials(4, 5, 42))
     parts.append(gen_monomials(4, 3, 35))
     open(out, "w").write("\n".join(parts))

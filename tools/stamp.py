@@ -42,10 +42,11 @@ def main():
     mask = torch.ones(B, 1, H, W, dtype=torch.uint8, device=dev)
     L, R, Hk = (torch.randn(B, n, device=dev) * 0.1 for n in (48, 48, 64))
     reg = torch.empty(B, device=dev)
+    poly = torch.randn(B, 3, 3, 126, device=dev) * 0.2
     nb = lib.curl_workspace_bytes(B, 160)
     ws = torch.empty(nb // 4, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    n_waves_max = B * ((H * W // 4 + 255) // 256) * 4
+    n_waves_max = B * max(((H * W // 4 + 255) // 256) * 4, H * 2 * 4)  # row-tiled ops: <= 2 blocks of <= 4 waves per row
     stamps = torch.zeros(n_waves_max * 8, dtype=torch.int64, device=dev)
     assert lib.curl_diag_set_stamps(stamps.data_ptr()) == 0
     cnt = [0]
@@ -62,6 +63,8 @@ def main():
         elif base == "lab_stage":
             rc = lib.curl_lab_stage_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                         ws.data_ptr(), nb, B, H, W, 16, flags, stream)
+        elif base == "trispace":
+            rc = lib.curl_trispace_fwd_f32(img.data_ptr(), poly.data_ptr(), out.data_ptr(), B, H, W, 126, flags, stream)
         elif base == "rgb_only":
             rc = lib.curl_adjust_rgb_f32(img.data_ptr(), R.data_ptr(), out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nb,
                                          B, H, W, 16, flags, stream)

@@ -43,6 +43,7 @@ VARIANTS = {
     "nopk_t3": ["-DCURL_PRIO_TRANS=3"],
     # polynomial model: its packed Horner code at raised priority too / the converters' helpers packed again
     "poly_splat": ["-DCURL_POLY_SPLAT_FIRST"],  # the chains' first fma from a compiler-built {c, c} pair (v_mov per odd c)
+    "poly_stage_r1": ["-DCURL_POLY_STAGE_GLOBAL"],  # row folds read global memory; pixel loads after the staging barrier
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
