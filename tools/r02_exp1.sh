@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round-2 experiment 1 (GPU box): how the VALU issues mixed streams, the in-kernel clock, A/B of experiment builds.
+# (Taken on the round-1 code, which was the default then; to repeat it on that code: VARIANT=r1_stamp for stamp.py,
+# CURL_HIP_LIB=curl_amd/lib/variants/libcurlhip_r1.so for valu_only.py and bench.py.)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r02_exp1
