@@ -92,3 +92,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "curl_oracle" not in txt and "libcurl_twin" not in txt, f
+
+
+def test_row_slab_entries_validate_before_any_hip_call():
+    """curl_layer_fwd_slab_f32 / curl_trispace_fwd_slab_f32: the slab must lie inside the image (CURL_E_SHAPE = -2)."""
+    from curl_amd import _lib
+    lib = _lib.load()
+    fake = ctypes.c_void_p(4096)
+    for row0, rows in ((-1, 2), (0, 0), (6, 4), (8, 1)):
+        assert lib.curl_layer_fwd_slab_f32(fake, None, 0, fake, fake, fake, fake, None, fake, 1 << 20, 1, 8, 8, row0, rows,
+                                           16, 16, 16, 0, None) == -2
+        assert b"slab" in lib.curl_last_error()
+        assert lib.curl_trispace_fwd_slab_f32(fake, fake, fake, 1, 8, 8, row0, rows, 126, 0, None) == -2
+    assert lib.curl_trispace_fwd_slab_f32(fake, fake, fake, 1, 8, 8, 0, 4, 100, 0, None) == -3  # num_coeffs
+    assert lib.curl_layer_fwd_slab_f32(fake, None, 0, fake, fake, fake, fake, None, fake, 1 << 20, 1, 8, 8, 0, 4,
+                                       16, 16, 16, 0x3, None) == -6  # flags
