@@ -204,6 +204,34 @@ def accuracy_vs_oracle(ops, device):
     }
 
 
+def end_to_end(ops, device, sets, masks, steps=5):
+    """BASELINE configs[1]/[2] as a user runs them: GCURLNet = encoder (timm's efficientnetv2_rw_s architecture on stock
+    PyTorch-ROCm, random init, fp32, fed the 320x320 view as infer.py:32-36 does) -> 160 knots -> the fused layer at
+    full resolution.  Context for the headline: how the per-pixel path compares with the encoder in one inference batch."""
+    from curl_amd import model
+    img = sets[0][0]
+    net = model.GCURLNet(encoder_size=320).to(device).eval()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    enc_ms, lay_ms = [], []
+    with torch.no_grad():
+        for i in range(steps + 2):
+            ev[0].record()
+            knots = net.predict_knots(img)
+            ev[1].record()
+            L, R, Hk = knots[:, :48], knots[:, 48:96], knots[:, 96:]
+            net.curllayer(img, masks["ones"], L, R, Hk)
+            ev[2].record()
+            torch.cuda.synchronize(device)
+            if i >= 2:
+                enc_ms.append(ev[0].elapsed_time(ev[1]))
+                lay_ms.append(ev[1].elapsed_time(ev[2]))
+    e, l = sorted(enc_ms)[len(enc_ms) // 2], sorted(lay_ms)[len(lay_ms) // 2]
+    B = img.shape[0]
+    return {"model": "GCURLNet: efficientnetv2_rw_s encoder (random init, fp32, stock PyTorch-ROCm) on the 320x320 view + "
+                     "fused CURLLayer at 1500x1000", "batch": B, "encoder_ms": e, "curve_layer_ms": l,
+            "ms_per_batch": e + l, "images_per_s": B / ((e + l) * 1e-3), "curve_layer_share": l / (e + l)}
+
+
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -391,6 +419,10 @@ def main():
         if not args.no_extras:
             line["other_workloads"] = others
             line["accuracy"] = accuracy_vs_oracle(ops, device)
+            try:
+                line["end_to_end"] = end_to_end(ops, device, sets, masks)
+            except Exception as e:  # context only: never at the expense of the line
+                line["end_to_end"] = {"error": repr(e)}
             if world == 1:
                 line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -69,7 +69,8 @@ def apply_row_slab(layer, img, mask, L, R, H, rank, world, out=None):
         n = [getattr(layer, a, None) for a in ("num_lab_points", "num_rgb_points", "num_hsv_points")]
         if None not in n:
             L, R, H = L[:, :n[0]], R[:, :n[1]], H[:, :n[2]]  # model.py:153,159,165
-        _, reg = ops.curl_layer_forward_rows(img, mask, L, R, H, (r0, r1), out)
+        flags = ops.F_PWL if getattr(layer, "paper_pwl", False) else 0  # CURLLayer(paper_pwl=True): the non-parity option
+        _, reg = ops.curl_layer_forward_rows(img, mask, L, R, H, (r0, r1), out, flags=flags)
         return out, reg, (r0, r1)
     sub = img[:, :, r0:r1, :].contiguous()
     sub_mask = None if mask is None else mask[:, :, r0:r1, :].contiguous()

@@ -14,4 +14,9 @@ crit = model.CURLLoss().cuda()
 crop, cmask = img[:, :, :256, :256].contiguous(), mask[:, :, :256, :256].contiguous()
 loss = crit(net(crop, cmask), crop, cmask)
 loss.backward()
+from curl_amd import shard
+both = torch.empty_like(img)
+for rank in range(2):  # the split-pixels layout: every "rank" enhances its row slab of every image, in place
+    shard.apply_row_slab(model.CURLLayer(), img, mask, L, R, H, rank, 2, out=both)
+assert torch.equal(both, out)
 print("ok", tuple(out.shape), float(psnr), float(loss.detach()))
