@@ -1,5 +1,5 @@
 """Static FLOP and VALU-issue counts of a kernel's hot basic block from hipcc's assembly (the numbers bench.py's
-`valu` rooflines use; DESIGN.md 5).
+`valu` rooflines use; DESIGN.md 3c).
 
     hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-math-errno -S --cuda-device-only -o /tmp/curl.s curl_amd/csrc/curl_kernels.hip
     python tools/flops_from_isa.py /tmp/curl.s 'stream_kernelI7OpLayerLi4ELi1ELi1ELb1ELi0E' [px_per_lane=4]
@@ -7,7 +7,7 @@
 FLOPs per lane: v_pk_fma_f32 4, v_fma/v_fmac/v_fmamk/v_fmaak 2, v_pk_mul/v_pk_add 2, v_mul/v_add/v_sub/v_min/v_max/
 v_med3/v_min3/v_max3 (f32) 1, v_exp/v_log/v_rcp/v_rsq/v_sqrt 1; integer, bit, move, convert instructions 0.
 Issue cycles per wave-instruction per SIMD (tools/ubench/valu_rate.hip, issue_mix.hip): packed / min / max / med3 /
-cmp / cvt 4, transcendental 8, every other VALU 4 alone or 2 when it pairs with another wave's (DESIGN.md 5).
+cmp / cvt 4, transcendental 8, every other VALU 4 alone or 2 when it pairs with another wave's (DESIGN.md 3c).
 """
 import re
 import sys

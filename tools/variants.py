@@ -27,7 +27,7 @@ VARIANTS = {
     "nodep": ["-DCURL_DIAG_NO_DEP"],
     # scheduling fences around the transcendental runs removed
     "nofence": ["-DCURL_NO_FENCE"],
-    # ---- dual-issue record (curl_math.h, DESIGN.md 5) ----
+    # ---- dual-issue record (curl_math.h, DESIGN.md 3c) ----
     "r1": R1,
     # plain code at RAISED priority (the first guess; makes it worse)
     "r1_fast1": ["-DCURL_USE_PK", "-DCURL_EXP_PRIO=1"],
