@@ -131,6 +131,55 @@ def timed_run(step, sets, steps, warmup, dist, device):
     return wall, dev_ms, dev_min
 
 
+class BoardPower:
+    """Board power / shader clock from the card's hwmon files, sampled in a thread while a timed region runs (context for
+    the roofline: the fused kernels run at the board's power cap).  Silent if the files are not there."""
+
+    def __init__(self):
+        import glob
+        self.files = {}
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for name in ("power1_average", "power1_input", "power1_cap", "freq1_input"):
+                p = os.path.join(d, name)
+                if os.path.exists(p):
+                    self.files.setdefault(name, p)
+        self.samples, self._stop, self._th = [], False, None
+
+    @staticmethod
+    def _read(p):
+        try:
+            return int(open(p).read().strip())
+        except Exception:
+            return None
+
+    def __enter__(self):
+        import threading
+        if self.files:
+            def loop():
+                while not self._stop:
+                    self.samples.append({k: self._read(p) for k, p in self.files.items()})
+                    time.sleep(0.02)
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+
+    def summary(self):
+        pw = [s.get("power1_average") or s.get("power1_input") for s in self.samples]
+        pw = [p for p in pw if p]
+        fq = [s["freq1_input"] for s in self.samples if s.get("freq1_input")]
+        cap = next((s["power1_cap"] for s in self.samples if s.get("power1_cap")), None)
+        if not pw:
+            return None
+        return {"board_power_W_mean": sum(pw) / len(pw) / 1e6, "board_power_cap_W": cap / 1e6 if cap else None,
+                "shader_clock_MHz_mean": sum(fq) / len(fq) / 1e6 if fq else None, "samples": len(pw),
+                "source": "amdgpu hwmon power1_*, freq1_input sampled every 20 ms over the settle, warm-up and timed steps"}
+
+
 def cold_first_launch_us(step, sets, device):
     """What a caller issuing ONE batch after an idle gap sees: the chip idles for half a second, then one step is
     timed with events on the launch stream (the steady-state figures come after CLOCK_SETTLE_LAUNCHES launches)."""
@@ -371,7 +420,9 @@ def main():
         bpp = w["bpp"]
         step = make_step(name, ops, masks)
         cold_us = cold_first_launch_us(step, sets, device) if cold else None
-        wall, dev_ms, dev_ms_min = timed_run(step, sets, steps, warmup, dist, device)
+        with BoardPower() as bp:
+            wall, dev_ms, dev_ms_min = timed_run(step, sets, steps, warmup, dist, device)
+        power = bp.summary() if rank == 0 else None
         mpix = world * npx_rank * steps / wall / 1e6
         gbps = npx_rank * bpp / (dev_ms * 1e-3) / 1e9
         tflops = npx_rank * w["flop_px"] / (dev_ms * 1e-3) / 1e12
@@ -388,6 +439,8 @@ def main():
                "device_ms_per_step_min_over_ranks": dev_ms_min, "roofline": roof}
         if cold_us is not None:
             res["cold_first_launch_us"] = cold_us
+        if power is not None:
+            res["power"] = power
         return res
 
     main_res = measure(args.workload, args.steps, args.warmup, cold=True)
@@ -414,6 +467,8 @@ def main():
             "gpus_visible": n_dev,
             "roofline": main_res["roofline"],
         }
+        if "power" in main_res:
+            line["power"] = main_res["power"]
         if n_dev < world:
             line["rehearsal"] = f"{world} ranks share {n_dev} GPU(s) over {backend}: not a scaling measurement"
         if not args.no_extras:
