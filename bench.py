@@ -135,10 +135,19 @@ class BoardPower:
     """Board power / shader clock from the card's hwmon files, sampled in a thread while a timed region runs (context for
     the roofline: the fused kernels run at the board's power cap).  Silent if the files are not there."""
 
-    def __init__(self):
+    def __init__(self, device_index=0):
         import glob
         self.files = {}
+        want = None
+        try:  # the host's sysfs shows every card of the node: pick the one this process computes on, by PCI address
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        except Exception:
+            pass
         for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            dev = os.path.realpath(os.path.join(d, "..", ".."))
+            if want is not None and want not in dev:
+                continue
             for name in ("power1_average", "power1_input", "power1_cap", "freq1_input"):
                 p = os.path.join(d, name)
                 if os.path.exists(p):
@@ -425,7 +434,7 @@ def main():
         if cold and rank == 0 and not args.no_extras:
             # the hwmon power reading is a slow average (the ~0.3 s timed region is too short for it): the same step
             # is kept running for 3 more seconds, outside the timing, and the second half of the samples is reported
-            with BoardPower() as bp:
+            with BoardPower(device.index or 0) as bp:
                 t_end = time.perf_counter() + 3.0
                 i = 0
                 while time.perf_counter() < t_end:

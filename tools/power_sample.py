@@ -20,7 +20,11 @@ from curl_amd import _lib, ops  # noqa: E402
 
 def hwmon_files():
     out = {}
-    for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+    pr = torch.cuda.get_device_properties(0)  # sysfs lists every card of the host: match this process's by PCI address
+    want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+    for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        if want not in os.path.realpath(os.path.join(d, "..", "..")):
+            continue
         for name in ("power1_average", "power1_input", "power1_cap", "freq1_input", "freq2_input", "temp1_input",
                      "temp2_input"):
             p = os.path.join(d, name)
