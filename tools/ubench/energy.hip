@@ -1,0 +1,193 @@
+// energy.hip -- board power while the VALU runs ONE kind of instruction, 8 waves per SIMD on every CU: energy per
+// wave-instruction by kind.  The fused layer runs at the board's 1400 W cap, so its time is its energy;
+// this probe says which instructions that energy goes to (is a transcendental 4 FMAs of energy, or 10?).
+//
+// Each pattern is launched back to back for SECONDS while a host thread samples the card's hwmon power file (the card is
+// found by its PCI address).  Reported: mean board power over the second half of the window, the instruction rate from
+// the wall clock, and (power - idle power) / rate = nJ per wave-instruction (64 lanes).
+// Build: hipcc -O3 --offload-arch=gfx950 -o energy energy.hip -lpthread        Run: ./energy [seconds per pattern]
+#include <hip/hip_runtime.h>
+#include <dirent.h>
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define A(i) "%" #i
+#define FMA(i) "v_fma_f32 " A(i) ", " A(i) ", %16, %17\n"
+#define FMAK(i) "v_fmamk_f32 " A(i) ", " A(i) ", 0x3f8ccccd, %17\n"
+#define MULK(i) "v_mul_f32 " A(i) ", 0x3f7fbe77, " A(i) "\n"
+#define SUB(i) "v_sub_f32 " A(i) ", %16, " A(i) "\n"
+#define ASHR(i) "v_ashrrev_i32 " A(i) ", 31, " A(i) "\n"
+#define BITOP(i) "v_bitop3_b32 " A(i) ", " A(i) ", %16, %17 bitop3:0xca\n"
+#define MOV(i) "v_mov_b32 " A(i) ", %16\n"
+#define MAX(i) "v_max_f32 " A(i) ", " A(i) ", %16\n"
+#define EXP(i) "v_exp_f32 " A(i) ", " A(i) "\n"
+#define LOG(i) "v_log_f32 " A(i) ", " A(i) "\n"
+#define RCP(i) "v_rcp_f32 " A(i) ", " A(i) "\n"
+#define SQRT(i) "v_sqrt_f32 " A(i) ", " A(i) "\n"
+#define PK8 "v_pk_fma_f32 %8, %8, %18, %19\nv_pk_fma_f32 %9, %9, %18, %19\nv_pk_fma_f32 %10, %10, %18, %19\nv_pk_fma_f32 %11, %11, %18, %19\n" \
+            "v_pk_fma_f32 %12, %12, %18, %19\nv_pk_fma_f32 %13, %13, %18, %19\nv_pk_fma_f32 %14, %14, %18, %19\nv_pk_fma_f32 %15, %15, %18, %19\n"
+#define NOP8 "s_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\n"
+#define X8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+
+template <int P>
+struct Pat;
+#define PATTERN(ID, NAME, BODY)                                                                                          \
+  template <>                                                                                                            \
+  struct Pat<ID> {                                                                                                       \
+    static constexpr const char* name = NAME;                                                                            \
+    static __device__ __forceinline__ void run(float (&a)[8], v2f (&p)[8], float c1, float c2, v2f k1, v2f k2) {         \
+      asm volatile(BODY                                                                                                  \
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),   \
+                     "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])    \
+                   : "v"(c1), "v"(c2), "v"(k1), "v"(k2));                                                                \
+    }                                                                                                                    \
+  };
+PATTERN(0, "s_nop (waves resident, VALU idle)", NOP8)
+PATTERN(1, "v_fma_f32 (3 VGPR operands)", X8(FMA))
+PATTERN(2, "v_fmamk_f32 (2 VGPR + literal)", X8(FMAK))
+PATTERN(3, "v_mul_f32 (1 VGPR + literal)", X8(MULK))
+PATTERN(4, "v_sub_f32", X8(SUB))
+PATTERN(5, "v_ashrrev_i32", X8(ASHR))
+PATTERN(6, "v_bitop3_b32", X8(BITOP))
+PATTERN(7, "v_mov_b32", X8(MOV))
+PATTERN(8, "v_max_f32", X8(MAX))
+PATTERN(9, "v_pk_fma_f32", PK8)
+PATTERN(10, "v_exp_f32", X8(EXP))
+PATTERN(11, "v_log_f32", X8(LOG))
+PATTERN(12, "v_rcp_f32", X8(RCP))
+PATTERN(13, "v_sqrt_f32", X8(SQRT))
+#define NPAT 14
+
+template <int P>
+__global__ __launch_bounds__(256) void k(float* out, float seed, int iters) {
+  float a[8];
+  v2f p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = seed + threadIdx.x * 1e-3f + i * 0.37f;  // values in [1, 4): log/exp/rcp stay finite under iteration? no --
+    p[i] = v2f{a[i], a[i] + 0.5f};                  // they are re-seeded from a mixing op below every iteration
+  }
+  const float c1 = seed * 0.999f, c2 = seed * 1e-3f;
+  const v2f k1 = v2f{c1, c1}, k2 = v2f{c2, c2};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) Pat<P>::run(a, p, c1, c2, k1, k2);
+    if (P >= 10) {  // keep transcendental inputs in a normal range (random-looking mantissas, exponent near 0)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a[i]) & 0x007fffffu) | 0x3f800000u);
+    }
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
+  if (s == 12345.678f) out[0] = s;
+}
+
+static std::string find_power_file() {
+  char bus[64] = {0};
+  hipDeviceGetPCIBusId(bus, sizeof(bus), 0);  // "0000:a4:00.0"
+  for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+  DIR* d = opendir("/sys/class/drm");
+  if (!d) return "";
+  std::string found;
+  while (dirent* e = readdir(d)) {
+    if (strncmp(e->d_name, "card", 4) != 0 || strchr(e->d_name, '-')) continue;
+    std::string dev = std::string("/sys/class/drm/") + e->d_name + "/device";
+    char real[PATH_MAX];
+    if (!realpath(dev.c_str(), real) || !strstr(real, bus)) continue;
+    std::string hw = dev + "/hwmon";
+    if (DIR* h = opendir(hw.c_str())) {
+      while (dirent* f = readdir(h))
+        if (!strncmp(f->d_name, "hwmon", 5)) {
+          for (const char* n : {"/power1_average", "/power1_input"}) {
+            std::string p = hw + "/" + f->d_name + n;
+            if (!access(p.c_str(), R_OK)) found = p;
+          }
+        }
+      closedir(h);
+    }
+  }
+  closedir(d);
+  return found;
+}
+
+static double read_watts(const std::string& f) {
+  FILE* fp = fopen(f.c_str(), "r");
+  if (!fp) return 0;
+  long long uw = 0;
+  if (fscanf(fp, "%lld", &uw) != 1) uw = 0;
+  fclose(fp);
+  return uw / 1e6;
+}
+
+static double g_idle = 0;
+
+template <int P>
+void run(float* d, const std::string& pf, double secs) {
+  const int wps = 8, blocks = 256 * wps, iters = 4096;  // 8 x 8 x 4096 = 262144 instructions per wave and launch
+  std::atomic<bool> stop{false};
+  std::vector<double> w;
+  std::thread th([&] {
+    while (!stop) {
+      w.push_back(read_watts(pf));
+      usleep(20000);
+    }
+  });
+  auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k<P>, dim3(blocks), dim3(256), 0, 0, d, 1.0f, iters);
+    launches += 20;
+    hipDeviceSynchronize();
+  }
+  double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  stop = true;
+  th.join();
+  double pw = 0;
+  size_t n0 = w.size() / 2;
+  for (size_t i = n0; i < w.size(); ++i) pw += w[i];
+  pw /= (double)(w.size() - n0);
+  const double instr = (double)launches * blocks * 4.0 * 64.0 * iters;  // wave-instructions, chip-wide
+  const double rate = instr / el;
+  if (P == 0) g_idle = pw;
+  printf("%-34s %7.1f W  %8.3f G wave-instr/s  %6.2f cyc/instr/SIMD @2.4GHz", Pat<P>::name, pw, rate / 1e9,
+         1024.0 * 2.4e9 / rate);
+  if (P > 0) printf("  %7.2f nJ per wave-instruction over the resident-idle level", (pw - g_idle) / rate * 1e9);
+  printf("\n");
+  fflush(stdout);
+}
+
+template <int P>
+struct RunAll {
+  static void go(float* d, const std::string& pf, double s) {
+    RunAll<P - 1>::go(d, pf, s);
+    run<P>(d, pf, s);
+  }
+};
+template <>
+struct RunAll<-1> {
+  static void go(float*, const std::string&, double) {}
+};
+
+int main(int argc, char** argv) {
+  double secs = argc > 1 ? atof(argv[1]) : 3.0;
+  float* d;
+  hipMalloc(&d, 4096);
+  std::string pf = find_power_file();
+  printf("power file: %s\n", pf.c_str());
+  if (pf.empty()) return 1;
+  usleep(500000);
+  printf("idle (no kernel): %.1f W\n", read_watts(pf));
+  RunAll<NPAT - 1>::go(d, pf, secs);
+  return 0;
+}
