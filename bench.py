@@ -242,6 +242,7 @@ def accuracy_vs_oracle(ops, device):
         "sample": "1 x 1500x1000 frame, knots N(0,0.1), bool disk mask, vs oracle (fp32 reference arithmetic)",
         "max_abs_err": float(d.max()),
         "frac_px_over_1e-5": float(over.double().mean()),
+        "frac_allclose_rtol1e-5_atol1e-6": float((d <= 1e-6 + 1e-5 * ref.double().abs()).double().mean()),
         # the reference is discontinuous on the hue seam (g == b with r maximal: hue 0 <-> 1 in front of a non-periodic
         # hue curve): there its float32 and float64 evaluations land on different sides -- counted, then set aside
         "px_where_ref32_and_ref64_take_different_hue_branches": int(((noise > 1e-3).any(1)).sum()),
