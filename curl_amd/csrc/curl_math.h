@@ -65,12 +65,12 @@ CURL_HD float clampf(float x, float lo, float hi) {
 CURL_HD float clamp01(float x) { return clampf(x, 0.0f, 1.0f); }
 
 // to_tensor's byte -> float: b / 255 correctly rounded, for b = 0..255 held exactly in a float, without the
-// ~10-instruction IEEE division: one Newton correction of b * fl(1/255) (all 256 values checked: test_twin_math).
+// ~10-instruction IEEE division: 1/255 as a float pair (hi + lo), b*lo rounded, then ONE fma b*hi + that -- equal to
+// the division for all 256 bytes (test_twin_math checks them; the plain product b*fl(1/255) is wrong for 126 of them).
 CURL_HD float u8_to_unit(float b) {
-  const float r = 1.0f / 255.0f;
-  float q = b * r;
-  float e = fmaf(-q, 255.0f, b);
-  return fmaf(e, r, q);
+  const float hi = (float)(1.0 / 255.0);
+  const float lo = (float)(1.0 / 255.0 - (double)hi);
+  return fmaf(b, hi, b * lo);
 }
 // n / d for small non-negative integers held in floats (pixel column / width): a Newton-corrected multiply by
 // rd = 1/d instead of the ~10-instruction IEEE division; equal to the division for every d <= 8192, n < d
