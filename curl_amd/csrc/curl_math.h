@@ -333,9 +333,42 @@ CURL_HD void rsub_run(float (&y)[M], float k, const float (&a)[M]) {
   for (int i = 0; i < M; ++i) y[i] = k - a[i];
 #endif
 }
+// The threshold selects of the converters (x <= thr ? a : b, twelve per pixel) on the device: v_cmp_le_f32_e64 into an
+// SGPR pair + v_cndmask_b32_e64 (the VOP3 form with its mask in SGPRs issues in 4 cycles; it is the VOP2 form with the
+// mask in VCC, what hipcc emits for `?:`, that takes 23).  Two instructions with two VGPR reads each instead of
+// sub / ashr / bitop3: 750 instead of 798 instructions per wave and ~0.7 nJ less per select (tools/ubench/energy.hip),
+// which is what counts under the board's power cap: layer 239.7 -> 236.8 us, Lab stage 199.1 -> 197.3 us on one box
+// (profiles/r02/select_cndmask_ab.log).  -DCURL_SELECT_BITWISE rebuilds the sign-bit form (which the host twin uses:
+// same values, also for x == thr; a NaN takes the second branch here, as the reference's `x <= thr` mask does).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CURL_SELECT_BITWISE)
+#define CURL_SELECT_CNDMASK 1
+#endif
+#if defined(CURL_SELECT_CNDMASK)
+__device__ __forceinline__ float select_le_hw(float x, float thr, float a, float b) {
+  unsigned long long m;
+  float r;
+  asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(thr));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+// (c < mx) ? +0 : val -- the "[c == max]" factor of the hue terms (c <= mx always holds there)
+__device__ __forceinline__ float zero_if_less_hw(float c, float mx, float val) {
+  unsigned long long m;
+  float r;
+  asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(c), "v"(mx));
+  asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(r) : "v"(val), "s"(m));
+  return r;
+}
+#endif
+
 // out = (x <= thr) ? a : b  element-wise (thr scalar)
 template <int M>
 CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, const float (&a)[M], const float (&b)[M]) {
+#if defined(CURL_SELECT_CNDMASK)
+#pragma unroll
+  for (int i = 0; i < M; ++i) out[i] = select_le_hw(x[i], thr, a[i], b[i]);
+  return;
+#endif
   float d[M];
   rsub_run(d, thr, x);
 #pragma unroll
@@ -481,8 +514,13 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
       g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
       lin[i] = clamp01(v[i] * vconst(12.92f));
     }
+#if defined(CURL_SELECT_CNDMASK)
+#pragma unroll
+    for (int i = 0; i < 3 * N; ++i) v[i] = select_le_hw(v[i], kLinThr, lin[i], g[i]);
+#else
 #pragma unroll
     for (int i = 0; i < 3 * N; ++i) v[i] = blend(neg_mask(d[i]), g[i], lin[i]);
+#endif
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -525,9 +563,15 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum.
     // [c == mx] as a bit mask: c - mx is negative exactly when c is NOT the maximum (+0 when it is), so one
     // arithmetic shift gives the complement mask and one and-not applies it.
+#if defined(CURL_SELECT_CNDMASK) && !defined(CURL_HUE_BITWISE)
+    float t0 = zero_if_less_hw(r[i], mx[i], (g[i] - b[i]) * dfi);
+    float t1 = zero_if_less_hw(g[i], mx[i], fmaf(b[i] - r[i], dfi, 2.0f));
+    float t2 = zero_if_less_hw(b[i], mx[i], fmaf(r[i] - g[i], dfi, 4.0f));
+#else
     float t0 = drop_if(neg_mask(r[i] - mx[i]), (g[i] - b[i]) * dfi);
     float t1 = drop_if(neg_mask(g[i] - mx[i]), fmaf(b[i] - r[i], dfi, 2.0f));
     float t2 = drop_if(neg_mask(b[i] - mx[i]), fmaf(r[i] - g[i], dfi, 4.0f));
+#endif
     int live = neg_mask(nd[i]);
     float h = keep_if(live, (t0 + t1) + t2);  // df == 0 -> 0 (colors.py:221)
     // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6

@@ -16,7 +16,7 @@ from curl_amd import build as B  # noqa: E402
 OUT_DIR = os.path.join(ROOT, "curl_amd", "lib", "variants")
 
 # name -> extra compiler switches
-R1 = ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=0"]  # the round-1 code: packed helpers, every wave at one priority
+R1 = ["-DCURL_USE_PK", "-DCURL_PRIO_TRANS=0", "-DCURL_SELECT_BITWISE"]  # the round-1 code: packed helpers, every wave at one priority
 
 VARIANTS = {
     "base": [],  # = the product library's switches
@@ -42,6 +42,8 @@ VARIANTS = {
     "nopk_t0": ["-DCURL_PRIO_TRANS=0"],
     "nopk_t3": ["-DCURL_PRIO_TRANS=3"],
     # polynomial model: its packed Horner code at raised priority too / the converters' helpers packed again
+    "sel_bitwise": ["-DCURL_SELECT_BITWISE"],
+    "hue_bitwise": ["-DCURL_HUE_BITWISE"],  # only the hue terms' [c == max] factors in the sign-bit form  # threshold selects as sub / ashr / bitop3 (default: v_cmp + v_cndmask_e64)
     "poly_splat": ["-DCURL_POLY_SPLAT_FIRST"],  # the chains' first fma from a compiler-built {c, c} pair (v_mov per odd c)
     "poly_stage_r1": ["-DCURL_POLY_STAGE_GLOBAL"],  # row folds read global memory; pixel loads after the staging barrier
     "poly1": ["-DCURL_PRIO_POLY=1"],
