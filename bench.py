@@ -60,21 +60,21 @@ WORKLOADS = {
     # latter FLOP per pixel counted from the kernel's hot block (tools/flops_from_isa.py: v_pk_fma 4 per lane,
     # v_fma 2, v_pk_mul/add 2, v_mul/add/sub/min/max 1, transcendental 1; integer / bit / move instructions 0).
     "layer": dict(desc="CURLLayer.forward fused 3-stage (RGB->Lab->RGB->HSV->RGB + residual), bool mask all ones "
-                       "(every pixel computed)", bpp=25.0, frag="OpLayer", mask="ones", bound="hbm", flop_px=213.0),
+                       "(every pixel computed)", bpp=25.0, frag="OpLayer", mask="ones", bound="hbm", flop_px=198.0),
     "layer_disk": dict(desc="same kernel, bool disk mask ~70 % coverage (fully masked wavefronts take the constant "
-                            "shortcut)", bpp=25.0, frag="OpLayer", mask="disk", bound="hbm", flop_px=213.0),
+                            "shortcut)", bpp=25.0, frag="OpLayer", mask="disk", bound="hbm", flop_px=198.0),
     "lab_stage": dict(desc="fused RGB->Lab->3 curves->mask->RGB (the kernel BASELINE's 70 % target names), bool mask "
-                           "all ones", bpp=25.0, frag="OpLabStage", mask="ones", bound="hbm", flop_px=136.0),
+                           "all ones", bpp=25.0, frag="OpLabStage", mask="ones", bound="hbm", flop_px=124.0),
     "rgb_only": dict(desc="RGB-only 3 curves (adjust_rgb, BASELINE configs[1]), no mask", bpp=24.0, frag="OpAdjust3",
                      mask=None, bound="hbm", flop_px=9.0),
     "trispace": dict(desc="TriSpaceRegNet per-pixel path (SURVEY 8f-1): 3 x degree-4 polynomial layers (126 coeffs x 3 "
                           "outputs) in RGB/Lab/HSV + converters + clamp, fused", bpp=24.0, frag="OpTriSpace", mask=None,
-                     bound="valu", flop_px=1480.0),
+                     bound="valu", flop_px=1464.0),
     "layer_u8": dict(desc="CURLLayer.forward on interleaved uint8 HWC in and out (SURVEY 8f-2: byte/255 and truncating "
                           "*255 fused), bool mask all ones", bpp=7.0, frag="OpLayer", mask="ones", bound="valu",
-                     flop_px=225.0),
+                     flop_px=210.0),
     "trispace_u8": dict(desc="TriSpaceRegNet per-pixel path on interleaved uint8 HWC in and out (infer.py:35-47 fused)",
-                        bpp=6.0, frag="OpTriSpace", mask=None, bound="valu", flop_px=1495.0),
+                        bpp=6.0, frag="OpTriSpace", mask=None, bound="valu", flop_px=1473.0),
 }
 
 
