@@ -9,7 +9,8 @@ from collections import defaultdict
 
 def load_counters(d):
     out = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:  # the newest pass only (gpurun_out/ accumulates over calls)
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
@@ -17,7 +18,8 @@ def load_counters(d):
 
 def load_trace(d):
     out = defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+    files = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     return out
