@@ -36,6 +36,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define SQRT(i) "v_sqrt_f32 " A(i) ", " A(i) "\n"
 #define PK8 "v_pk_fma_f32 %8, %8, %18, %19\nv_pk_fma_f32 %9, %9, %18, %19\nv_pk_fma_f32 %10, %10, %18, %19\nv_pk_fma_f32 %11, %11, %18, %19\n" \
             "v_pk_fma_f32 %12, %12, %18, %19\nv_pk_fma_f32 %13, %13, %18, %19\nv_pk_fma_f32 %14, %14, %18, %19\nv_pk_fma_f32 %15, %15, %18, %19\n"
+#define PKS8 "v_pk_fma_f32 %8, %8, %18, s[20:21]\nv_pk_fma_f32 %9, %9, %18, s[20:21]\nv_pk_fma_f32 %10, %10, %18, s[20:21]\nv_pk_fma_f32 %11, %11, %18, s[20:21]\n" \
+             "v_pk_fma_f32 %12, %12, %18, s[20:21]\nv_pk_fma_f32 %13, %13, %18, s[20:21]\nv_pk_fma_f32 %14, %14, %18, s[20:21]\nv_pk_fma_f32 %15, %15, %18, s[20:21]\n"
+#define PKB8 "v_pk_fma_f32 %8, %8, %18, %19 op_sel_hi:[1,1,0]\nv_pk_fma_f32 %9, %9, %18, %19 op_sel:[0,0,1]\nv_pk_fma_f32 %10, %10, %18, %19 op_sel_hi:[1,1,0]\nv_pk_fma_f32 %11, %11, %18, %19 op_sel:[0,0,1]\n" \
+             "v_pk_fma_f32 %12, %12, %18, %19 op_sel_hi:[1,1,0]\nv_pk_fma_f32 %13, %13, %18, %19 op_sel:[0,0,1]\nv_pk_fma_f32 %14, %14, %18, %19 op_sel_hi:[1,1,0]\nv_pk_fma_f32 %15, %15, %18, %19 op_sel:[0,0,1]\n"
+#define FMAS(i) "v_fma_f32 " A(i) ", " A(i) ", %16, s20\n"
 #define NOP8 "s_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\n"
 #define X8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 
@@ -49,7 +54,8 @@ struct Pat;
       asm volatile(BODY                                                                                                  \
                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),   \
                      "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])    \
-                   : "v"(c1), "v"(c2), "v"(k1), "v"(k2));                                                                \
+                   : "v"(c1), "v"(c2), "v"(k1), "v"(k2)                                                                  \
+                   : "s20", "s21");                                                                \
     }                                                                                                                    \
   };
 PATTERN(0, "s_nop (waves resident, VALU idle)", NOP8)
@@ -66,7 +72,10 @@ PATTERN(10, "v_exp_f32", X8(EXP))
 PATTERN(11, "v_log_f32", X8(LOG))
 PATTERN(12, "v_rcp_f32", X8(RCP))
 PATTERN(13, "v_sqrt_f32", X8(SQRT))
-#define NPAT 14
+PATTERN(14, "v_pk_fma_f32, addend an SGPR pair", PKS8)
+PATTERN(15, "v_pk_fma_f32, addend broadcast by op_sel", PKB8)
+PATTERN(16, "v_fma_f32, addend an SGPR", X8(FMAS))
+#define NPAT 17
 
 template <int P>
 __global__ __launch_bounds__(256) void k(float* out, float seed, int iters) {
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(256) void k(float* out, float seed, int iters) {
   }
   const float c1 = seed * 0.999f, c2 = seed * 1e-3f;
   const v2f k1 = v2f{c1, c1}, k2 = v2f{c2, c2};
+  asm volatile("s_mov_b32 s20, 0x3a83126f\ns_mov_b32 s21, 0x3a83126f" ::: "s20", "s21");
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) Pat<P>::run(a, p, c1, c2, k1, k2);
