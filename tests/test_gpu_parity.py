@@ -982,3 +982,28 @@ def test_config1_real_image_pixels_on_the_hip_path(ops, dev, golden):
     assert (N(u8).astype(int) - c["out_u8_corner"].astype(int)).__abs__().max() <= 1
     out_none, _ = ops.curl_layer_forward(x, None, L, R, Hk)
     assert torch.equal(out_none, out)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 60), (1, 33, 65), (2, 7, 9)])
+def test_tuning_flags_do_not_change_results(ops, dev, shape):
+    """CURL_F_TUNE_*: float4 groups per lane (1, 2, 4), threads per workgroup (256, 128, 64) and plain instead of
+    non-temporal accesses are scheduling choices -- every combination must give bit-identical images."""
+    from curl_amd import _lib
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+    ref, reg = ops.curl_layer_forward(img, mask, L, R, Hk)
+    ls0, _ = ops.lab_stage(img, mask, L)
+    rgb0, _ = ops.adjust_rgb(img, R)
+    for u in (1, 2, 4):
+        for b in (0, 1, 2):
+            for nt in (0, _lib.F_TUNE_NO_NT):
+                fl = (u << _lib.F_TUNE_UNROLL_SHIFT) | (b << _lib.F_TUNE_BLOCK_SHIFT) | nt
+                out, r2 = ops.curl_layer_forward(img, mask, L, R, Hk, flags=fl)
+                assert torch.equal(out, ref) and torch.equal(r2, reg), hex(fl)
+                assert torch.equal(ops.lab_stage(img, mask, L, flags=fl)[0], ls0), hex(fl)
+                assert torch.equal(ops.adjust_rgb(img, R, flags=fl)[0], rgb0), hex(fl)
+    with pytest.raises(ValueError):
+        ops.curl_layer_forward(img, mask, L, R, Hk, flags=3 << _lib.F_TUNE_BLOCK_SHIFT)
