@@ -111,6 +111,9 @@ struct PolyEval<4> {  // 3 colour channels + x/W: the per-row collapsed form of 
   template <class F, bool SEQ, int NP>
   static CURL_HD void eval(F (&out)[NP], const F (&v)[NP][4], const float* c) { poly_d4_v4<F, SEQ, NP>(out, v, c); }
   static CURL_HD int order(int pos) { return kPolyOrder_d4_v4[pos]; }
+  static constexpr int kChunk = 35, kChunks = 2;  // the x-folded coefficient gradient (coef_grad_accumulate_foldx)
+  template <int C>
+  static CURL_HD void monomials(float (&m)[35], const float (&pw)[4][5]) { mono_d4_v4<C>(m, pw); }
 };
 template <>
 struct PolyEval<3> {
@@ -403,6 +406,72 @@ CURL_HD void coef_grad_accumulate(float (&acc)[3][PolyEval<V>::kChunk], const fl
   for (int o = 0; o < 3; ++o)
 #pragma unroll
     for (int j = 0; j < T; ++j) acc[o][j] = fmaf(gP[o], m[j], acc[o][j]);
+}
+
+// The same for the spatial polynomial with the COLUMN coordinate folded out (PolyFoldX, poly_horner.inc): a thread that
+// walks down one image column has one x, so it accumulates over the 70 monomials of (c0, c1, c2, y) -- chunk C of 35 --
+// and expands by the powers of x once at the end (coef_grad_expand_foldx): 35 monomials + 105 FMAs per pixel and chunk,
+// two chunks, instead of 42 + 126 and three.
+// The accumulators are PAIRS (35 monomials padded to 36): on gfx950 one v_pk_fma_f32 per pair, the same 18 monomial pairs
+// for the three outputs.  (Left to hipcc's vectoriser over 3 x 35 floats, the second output's pairs straddled the
+// first's and the monomial products were packed too: 70 moves and shuffles per step next to 51 packed FMAs.)
+constexpr int kFoldXPairs = 18;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef curl_f2 foldx_pair;
+#else
+struct foldx_pair {
+  float x, y;
+};
+#endif
+template <int C>
+CURL_HD void coef_grad_accumulate_foldx(foldx_pair (&acc)[3][kFoldXPairs], const float (&c)[3], float y, const float (&gP)[3]) {
+  const float v[4] = {c[0], c[1], c[2], y};
+  float pw[4][5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pw[k][0] = 1.0f;
+    pw[k][1] = v[k];
+    pw[k][2] = v[k] * v[k];
+    pw[k][3] = pw[k][2] * v[k];
+    pw[k][4] = pw[k][2] * pw[k][2];
+  }
+  float m[2 * kFoldXPairs];
+  {
+    float m35[35];
+    PolyEval<4>::template monomials<C>(m35, pw);
+#pragma unroll
+    for (int j = 0; j < 2 * kFoldXPairs; ++j) m[j] = j < 35 ? m35[j] : 0.0f;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int j = 0; j < 35; ++j) asm volatile("" : "+v"(m[j]));  // scalar products, each in a register of its own choosing
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const curl_f2 g = {gP[o], gP[o]};
+#pragma unroll
+    for (int k = 0; k < kFoldXPairs; ++k) {
+      const curl_f2 mk = {m[2 * k], m[2 * k + 1]};
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[o][k]) : "v"(g), "v"(mk));
+    }
+  }
+#else
+  for (int o = 0; o < 3; ++o)
+    for (int k = 0; k < kFoldXPairs; ++k) {
+      acc[o][k].x = fmaf(gP[o], m[2 * k], acc[o][k].x);
+      acc[o][k].y = fmaf(gP[o], m[2 * k + 1], acc[o][k].y);
+    }
+#endif
+}
+// e[i] = x^j_i * acc[m'_i] for slice S of chunk C's (monomial, x power) pairs; kPolyFoldXIndex[C][S][i] names the
+// reference coefficient each one is the gradient of
+template <int C, int S>
+CURL_HD void coef_grad_expand_foldx(float (&e)[PolyFoldX<C>::kSlice], const foldx_pair (&acc)[kFoldXPairs], float x) {
+  const float x2 = x * x;
+  const float xp[5] = {1.0f, x, x2, x2 * x, x2 * x2};
+  float a[35];
+#pragma unroll
+  for (int j = 0; j < 35; ++j) a[j] = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
+  foldx_expand<C, S>(e, a, xp);
 }
 
 }  // namespace curlm

@@ -72,6 +72,13 @@ def _one_device(fn):
     return wrapper
 
 
+def _coeffs32(coeffs):
+    """float32, contiguous, and 8-byte aligned (the kernels copy the table into LDS as 8-byte pairs; a view that starts
+    at an odd float of its storage is copied)."""
+    c = coeffs.to(torch.float32).contiguous()
+    return c.clone() if c.data_ptr() % 8 else c
+
+
 def _check_out(out, img):
     """A caller-supplied `out` is written in place by the kernel: anything but a contiguous float32 tensor of the
     image's shape on the image's device would be an out-of-bounds or foreign-device write."""
@@ -326,7 +333,7 @@ def trispace_forward_rows(img, coeffs, rows, out, residual_only=False):
     _need_device(coeffs, "coeffs")
     if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
         raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
-    c = coeffs.to(torch.float32).contiguous()
+    c = _coeffs32(coeffs)
     out = _check_out(out, img)
     rc = lib.curl_trispace_fwd_slab_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, r0, n, c.shape[3],
                                         _lib.F_RESIDUAL_ONLY if residual_only else 0, _stream(img))
@@ -378,7 +385,7 @@ def trispace_forward(img, coeffs, residual_only=False, flags=0):
     _need_device(coeffs, "coeffs")
     if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
         raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
-    c = coeffs.to(torch.float32).contiguous()
+    c = _coeffs32(coeffs)
     out = torch.empty_like(img)
     rc = lib.curl_trispace_fwd_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, c.shape[3],
                                    flags | (_lib.F_RESIDUAL_ONLY if residual_only else 0), _stream(img))
@@ -392,7 +399,7 @@ def trispace_backward(img, coeffs, grad_out, residual_only=False):
     lib = _lib.load()
     img, grad_out = _image(img), _image(grad_out, "grad_out")
     B, _, H, W = img.shape
-    c = coeffs.to(torch.float32).contiguous()
+    c = _coeffs32(coeffs)
     nc = c.shape[3]
     g = torch.empty_like(c)
     nbytes = lib.curl_trispace_bwd_scratch_bytes(B, H, W, nc)
@@ -416,7 +423,7 @@ def poly_layer(img, coeffs):
     nc = 126 if V == 5 else 35
     if tuple(coeffs.shape) != (B, 3, nc):
         raise ValueError(f"coeffs must be [B={B},3,{nc}], got {tuple(coeffs.shape)}")
-    img, c = img.contiguous(), coeffs.to(torch.float32).contiguous()
+    img, c = img.contiguous(), _coeffs32(coeffs)
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
     _lib.check(lib.curl_poly_layer_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, V, _stream(img)),
                "curl_poly_layer_f32")
@@ -503,7 +510,7 @@ def trispace_forward_u8hwc(img_u8, coeffs, white_mask=None):
     _need_device(coeffs, "coeffs")
     if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
         raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
-    c = coeffs.to(torch.float32).contiguous()
+    c = _coeffs32(coeffs)
     wm = _white(white_mask, x)
     out = torch.empty_like(x)
     rc = lib.curl_trispace_fwd_u8hwc(x.data_ptr(), c.data_ptr(), _ptr(wm), out.data_ptr(), B, H, W, c.shape[3], 0,

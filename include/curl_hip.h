@@ -162,6 +162,8 @@ int curl_layer_bwd_f32(const float* img, const void* mask, int mask_kind,
  *           (model.py:336-415) or ChannelPolyLayer(degree=4) (model.py:206-333), as ONE pass over the pixels.
  * coeffs [B,3,3,num_coeffs] = the reshaped head output (model.py:523-526; [:,0]=R, [:,1]=L, [:,2]=H).
  * num_coeffs 126 = spatial model (5 variables: colour + x/W + y/H), 35 = non-spatial (3 variables).
+ * coeffs must be 8-byte aligned (CURL_E_SHAPE otherwise; true of any allocation's start): the kernels copy an image's
+ * table into LDS as 8-byte pairs.  The same holds for the u8 and backward entry points below.
  * Default output: clamp(img + residual, 0, 1); with CURL_F_RESIDUAL_ONLY the residual itself. */
 int curl_trispace_fwd_f32(const float* img, const float* coeffs, float* out, int B, int H, int W,
                           int num_coeffs, unsigned flags, curl_stream_t stream);

@@ -170,6 +170,14 @@ def twin():
             return g
 
         @staticmethod
+        def trispace_bwd_foldx(img, coeffs, gout, residual_only=False):
+            img, coeffs, gout = f32(img), f32(coeffs), f32(gout)
+            B, _, Hh, W = img.shape
+            g = np.empty_like(coeffs)
+            lib.twin_trispace_bwd_foldx(P(img), P(coeffs), P(gout), P(g), B, Hh, W, int(residual_only))
+            return g
+
+        @staticmethod
         def div_small_mismatches(dmax):
             lib.twin_div_small_mismatches.restype = ctypes.c_long
             return int(lib.twin_div_small_mismatches(int(dmax)))

@@ -107,3 +107,18 @@ def test_row_slab_entries_validate_before_any_hip_call():
     assert lib.curl_trispace_fwd_slab_f32(fake, fake, fake, 1, 8, 8, 0, 4, 100, 0, None) == -3  # num_coeffs
     assert lib.curl_layer_fwd_slab_f32(fake, None, 0, fake, fake, fake, fake, None, fake, 1 << 20, 1, 8, 8, 0, 4,
                                        16, 16, 16, 0x3, None) == -6  # flags
+
+
+def test_polynomial_entries_refuse_a_misaligned_coefficient_table():
+    """The polynomial kernels copy an image's coefficient table into LDS as 8-byte pairs: a table at an odd float address is
+    an argument error (CURL_E_SHAPE = -2) before any launch; the Python wrappers copy such a view instead."""
+    from curl_amd import _lib
+    lib = _lib.load()
+    fake, odd = ctypes.c_void_p(4096), ctypes.c_void_p(4096 + 4)
+    assert lib.curl_trispace_fwd_f32(fake, odd, fake, 1, 8, 8, 126, 0, None) == -2
+    assert b"8-byte aligned" in lib.curl_last_error()
+    assert lib.curl_trispace_fwd_slab_f32(fake, odd, fake, 1, 8, 8, 0, 4, 126, 0, None) == -2
+    assert lib.curl_trispace_fwd_u8hwc(fake, odd, None, fake, 1, 8, 8, 126, 0, None) == -2
+    assert lib.curl_trispace_bwd_f32(fake, odd, fake, fake, fake, 1 << 30, 1, 8, 8, 126, 0, None) == -2
+    src = open(os.path.join(ROOT, "curl_amd", "ops.py")).read()
+    assert src.count("coeffs.to(torch.float32).contiguous()") == 1 and src.count("_coeffs32(coeffs)") >= 5  # one helper, used everywhere

@@ -179,10 +179,13 @@ def test_curl_loss_with_msssim_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("nc,residual_only,shape", [(126, False, (2, 12, 20)), (126, True, (1, 70, 131)),
-                                                      (35, False, (3, 33, 65)), (126, False, (1, 130, 257))])
+                                                      (35, False, (3, 33, 65)), (126, False, (1, 130, 257)),
+                                                      (126, False, (1, 40, 128)), (126, True, (2, 37, 256)),
+                                                      (126, False, (1, 9, 600))])
 def test_trispace_backward_vs_oracle_autograd(ops, dev, nc, residual_only, shape):
     """d loss / d coeffs of the fused polynomial path (C ABI) vs autograd through the oracle; sizes straddle the
-    4096-pixel accumulation tile (1, 3 and 9 tiles, ragged)."""
+    accumulation tiles: the 4096-pixel tile of the non-spatial form; for the spatial form's column strips 64-, 128- and
+    256-column blocks (widths 20 / 131 / 257 / 600, 128, 256), one to five column blocks, one to three row tiles, ragged."""
     from oracle import curl_oracle as O
     g = torch.Generator().manual_seed(nc + residual_only + shape[1])
     B, H, W = shape
@@ -196,6 +199,20 @@ def test_trispace_backward_vs_oracle_autograd(ops, dev, nc, residual_only, shape
     assert rel(got, coeffs.grad) <= 2e-4
     again = ops.trispace_backward(img.to(dev), coeffs.detach().to(dev), w.to(dev), residual_only=residual_only)
     assert torch.equal(got, again)  # fixed-order reduction: bit-reproducible
+
+
+def test_trispace_backward_batch_geometry_consistent(ops, dev):
+    """The training crop batch (32 x 256 x 256: 24 rows per thread, 11 row tiles) against the same images one at a time
+    (16 rows per thread, 16 row tiles): the same sums in another order."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 32, 256, 256
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    coeffs = (torch.randn(B, 3, 3, 126, generator=g) * 0.3).to(dev)
+    w = torch.randn(B, 3, H, W, generator=g).to(dev)
+    got = ops.trispace_backward(img, coeffs, w)
+    for b in (0, 13, 31):
+        one = ops.trispace_backward(img[b:b + 1].contiguous(), coeffs[b:b + 1].contiguous(), w[b:b + 1].contiguous())
+        assert rel(got[b:b + 1], one) <= 2e-5
 
 
 def test_trispace_regnet_train_step(dev):

@@ -1,11 +1,15 @@
 """The polynomial per-pixel path: oracle vs the golden vectors produced by running the
 reference's own classes, the kernel arithmetic (host twin) vs both."""
+import os
+import re
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import curl_oracle as O
-from conftest import max_err
+from conftest import ROOT, max_err
 
 
 def t(a):
@@ -85,4 +89,45 @@ def test_twin_trispace_backward_vs_oracle_autograd(twin, nc, residual_only):
     (out * w).sum().backward()
     got = twin.trispace_bwd(img.numpy(), coeffs.detach().numpy(), w.numpy(), residual_only)
     ref = coeffs.grad.numpy()
+    assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_foldx_index_table_covers_every_coefficient_once():
+    """The x-fold of the coefficient gradient (tools/gen_poly_horner.py:gen_foldx): its (monomial, x power) pairs name each
+    of the 126 reference coefficients exactly once, and each pair multiplies out to that coefficient's monomial."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_poly_horner as gph
+    full, small = gph.powers(4, 5), gph.powers(4, 4)
+    text = open(os.path.join(ROOT, "curl_amd", "csrc", "poly_horner.inc")).read()
+    body = text[text.index("kPolyFoldXIndex[2][2][46]"):]
+    idx = [int(x, 0) for x in re.findall(r"0xFFFF|\d+", body[body.index("=") + 1:body.index(";")])]
+    live = [t for t in idx if t != 0xFFFF]
+    assert sorted(live) == list(range(126))
+    assigns = re.findall(r"if constexpr \(C == (\d) && S == (\d)\) \{(.*?)\n  \}", text[text.index("void foldx_expand"):], re.S)
+    seen = 0
+    for c, sl, blk in assigns:
+        for i, jl, j in re.findall(r"e\[(\d+)\] = a\[(\d+)\](?: \* xp\[(\d)\])?;", blk):
+            m = small[int(c) * 35 + int(jl)]
+            t = idx[(int(c) * 2 + int(sl)) * 46 + int(i)]
+            assert full[t] == m[:3] + (int(j or 0),) + m[3:], (c, sl, i)
+            seen += 1
+    assert seen == 126
+
+
+@pytest.mark.parametrize("residual_only", [False, True])
+def test_twin_trispace_backward_column_strips(twin, residual_only):
+    """The accumulation order of the HIP kernel's spatial backward (per column, x folded out, expanded at the end) gives
+    the gradient of the plain 126-monomial form, and the oracle's autograd."""
+    g = torch.Generator().manual_seed(7 + residual_only)
+    B, H, W = 2, 9, 14
+    img = torch.rand(B, 3, H, W, generator=g)
+    coeffs = (torch.randn(B, 3, 3, 126, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(B, 3, H, W, generator=g)
+    res = O.trispace_residual(img, coeffs[:, 0], coeffs[:, 1], coeffs[:, 2], spatial=True)
+    out = res if residual_only else O.generate_image(img, res)
+    (out * w).sum().backward()
+    ref = coeffs.grad.numpy()
+    got = twin.trispace_bwd_foldx(img.numpy(), coeffs.detach().numpy(), w.numpy(), residual_only)
+    plain = twin.trispace_bwd(img.numpy(), coeffs.detach().numpy(), w.numpy(), residual_only)
+    assert np.abs(got - plain).max() <= 2e-5 * np.abs(plain).max()
     assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()

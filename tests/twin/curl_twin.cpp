@@ -306,7 +306,57 @@ static void trispace_bwd_host(const float* img, const float* coeffs, const float
     for (int k = 0; k < 9 * NC; ++k) gcoef[(size_t)b * 9 * NC + k] = (float)acc[k];
   }
 }
+// The spatial form's accumulation as the HIP kernel does it (trispace_coef_grad_strip_kernel): per image column, sums over
+// the 70 monomials of (c0, c1, c2, y) down the rows, expanded by the powers of that column's x at the end.
+template <int C, int S>
+static void foldx_flush(const curlm::foldx_pair (&a)[curlm::kFoldXPairs], float x, double* dst) {
+  if constexpr (S < curlm::PolyFoldX<C>::kSlices) {
+    float e[curlm::PolyFoldX<C>::kSlice];
+    curlm::coef_grad_expand_foldx<C, S>(e, a, x);
+    for (int i = 0; i < curlm::PolyFoldX<C>::kSlice; ++i) {
+      unsigned t = curlm::kPolyFoldXIndex[C][S][i];
+      if (t != 0xFFFFu) dst[t] += e[i];
+    }
+    foldx_flush<C, S + 1>(a, x, dst);
+  }
+}
+static void trispace_bwd_host_foldx(const float* img, const float* coeffs, const float* gout, float* gcoef, int B, int H, int W,
+                                    int residual_only) {
+  constexpr int NC = 126;
+  const long HW = (long)H * W;
+  for (int b = 0; b < B; ++b) {
+    std::vector<double> acc(9 * NC, 0.0);
+    for (int col = 0; col < W; ++col) {
+      const float xw = (float)col / (float)W;
+      curlm::foldx_pair a0[3][3][curlm::kFoldXPairs] = {}, a1[3][3][curlm::kFoldXPairs] = {};
+      for (int row = 0; row < H; ++row) {
+        const long i = (long)row * W + col;
+        const float* p = img + (size_t)b * 3 * HW + i;
+        const float* g = gout + (size_t)b * 3 * HW + i;
+        const float yh = (float)row / (float)H;
+        float vars[3][3], gP[3][3];
+        trispace_bwd_px<5, false>(Px{p[0], p[HW], p[2 * HW]}, xw, yh, coeffs + (size_t)b * 9 * NC, Px{g[0], g[HW], g[2 * HW]},
+                                  residual_only != 0, vars, gP);
+        for (int s = 0; s < 3; ++s) {
+          curlm::coef_grad_accumulate_foldx<0>(a0[s], vars[s], yh, gP[s]);
+          curlm::coef_grad_accumulate_foldx<1>(a1[s], vars[s], yh, gP[s]);
+        }
+      }
+      for (int s = 0; s < 3; ++s)
+        for (int o = 0; o < 3; ++o) {
+          foldx_flush<0, 0>(a0[s][o], xw, acc.data() + (s * 3 + o) * NC);
+          foldx_flush<1, 0>(a1[s][o], xw, acc.data() + (s * 3 + o) * NC);
+        }
+    }
+    for (int k = 0; k < 9 * NC; ++k) gcoef[(size_t)b * 9 * NC + k] = (float)acc[k];
+  }
+}
 extern "C" {
+int twin_trispace_bwd_foldx(const float* img, const float* coeffs, const float* gout, float* gcoef, int B, int H, int W,
+                            int residual_only) {
+  trispace_bwd_host_foldx(img, coeffs, gout, gcoef, B, H, W, residual_only);
+  return 0;
+}
 int twin_trispace_bwd(const float* img, const float* coeffs, const float* gout, float* gcoef, int B, int H, int W, int V,
                       int residual_only) {
   if (V == 5) trispace_bwd_host<5>(img, coeffs, gout, gcoef, B, H, W, residual_only);

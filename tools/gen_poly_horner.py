@@ -216,6 +216,63 @@ def gen_fold(degree, nvars, order_small):
             f"constexpr PolyFoldRow kPolyFold_d{degree}_v{nvars}[{len(small)}] = {{\n  " + ",\n  ".join("{" + r + "}" for r in rows) + "};\n").replace("\\n", "\n")
 
 
+def gen_foldx(degree, nvars, chunk):
+    """Folding the variable BEFORE the last one out of the coefficient gradient (the backward's accumulation pass): a thread
+    that walks down one image column sees one value x of variable nvars-2 (column / width), so it accumulates
+    S[m'] = sum_rows g * m'(v0..v_{n-3}, y) over the monomials m' of the OTHER nvars-1 variables (70 instead of 126 for
+    degree 4) and expands d coef[(m', x^j)] = x^j * S[m'] once at the end.  Emitted: per chunk of `chunk` monomials m'
+    (reference order of nvars-1 variables) the pairs (m', j), cut into slices that fit the register file next to the
+    accumulators: foldx_expand<C, S>(e, a, xp) writes e[i] = a[m'_i] * xp[j_i], kPolyFoldXIndex[C][S][i] is the reference
+    index (nvars variables) of pair i (0xFFFF = padding)."""
+    full = {t: i for i, t in enumerate(powers(degree, nvars))}
+    small = powers(degree, nvars - 1)
+    n_chunks = (len(small) + chunk - 1) // chunk
+    per_chunk = []
+    for c in range(n_chunks):
+        pairs = []
+        for jl in range(chunk):
+            q = c * chunk + jl
+            if q >= len(small):
+                continue
+            m = small[q]
+            for j in range(degree - sum(m) + 1):
+                pairs.append((jl, j, full[m[:-1] + (j,) + m[-1:]]))
+        per_chunk.append(pairs)
+    max_slice = 48
+    geo = []
+    for pairs in per_chunk:
+        n_sl = (len(pairs) + max_slice - 1) // max_slice
+        geo.append((len(pairs), n_sl, (len(pairs) + n_sl - 1) // n_sl))
+    smax, lmax = max(g[1] for g in geo), max(g[2] for g in geo)
+    out = [f"// x-fold of the coefficient gradient (degree {degree}, {nvars} variables): chunks of {chunk} monomials of the other {nvars - 1}\n"
+           f"// variables, each expanded by the powers of variable {nvars - 2}; see tools/gen_poly_horner.py:gen_foldx",
+           "template <int C>\nstruct PolyFoldX;"]
+    for c, (n, n_sl, ln) in enumerate(geo):
+        out.append(f"template <>\nstruct PolyFoldX<{c}> {{\n  static constexpr int kPairs = {n}, kSlices = {n_sl}, kSlice = {ln};\n}};")
+    out.append(f"constexpr int kPolyFoldXChunks = {n_chunks}, kPolyFoldXMaxSlices = {smax}, kPolyFoldXMaxSlice = {lmax};")
+    out.append(f"template <int C, int S>\nCURL_HD void foldx_expand(float (&e)[PolyFoldX<C>::kSlice], const float (&a)[{chunk}], const float (&xp)[{degree + 1}]) {{")
+    rows = []
+    for c, (n, n_sl, ln) in enumerate(geo):
+        crow = []
+        for sl in range(smax):
+            part = per_chunk[c][sl * ln:(sl + 1) * ln] if sl < n_sl else []
+            if sl < n_sl:
+                out.append(f"  if constexpr (C == {c} && S == {sl}) {{")
+                for i in range(ln):
+                    if i < len(part):
+                        jl, j, _ = part[i]
+                        out.append(f"    e[{i}] = a[{jl}]" + (f" * xp[{j}];" if j else ";"))
+                    else:
+                        out.append(f"    e[{i}] = 0.0f;")
+                out.append("  }")
+            ent = [str(t) for _, _, t in part] + ["0xFFFF"] * (lmax - len(part))
+            crow.append("{" + ", ".join(ent) + "}")
+        rows.append("{" + ",\n   ".join(crow) + "}")
+    out.append("}")
+    out.append(f"constexpr unsigned short kPolyFoldXIndex[{n_chunks}][{smax}][{lmax}] = {{\n  " + ",\n  ".join(rows) + "};\n")
+    return "\n".join(out).replace("\\n", "\n")
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "curl_amd", "csrc", "poly_horner.inc")
@@ -234,6 +291,8 @@ def main():
     parts.append(gen_fold(4, 5, orders[4]))
     parts.append(gen_monomials(4, 5, 42))
     parts.append(gen_monomials(4, 3, 35))
+    parts.append(gen_monomials(4, 4, 35))
+    parts.append(gen_foldx(4, 5, 35))
     open(out, "w").write("\n".join(parts))
     print("wrote", out)
 

@@ -46,6 +46,8 @@ VARIANTS = {
     "hue_bitwise": ["-DCURL_HUE_BITWISE"],  # only the hue terms' [c == max] factors in the sign-bit form  # threshold selects as sub / ashr / bitop3 (default: v_cmp + v_cndmask_e64)
     "poly_splat": ["-DCURL_POLY_SPLAT_FIRST"],  # the chains' first fma from a compiler-built {c, c} pair (v_mov per odd c)
     "poly_stage_r1": ["-DCURL_POLY_STAGE_GLOBAL"],  # row folds read global memory; pixel loads after the staging barrier
+    "bwd_plain": ["-DCURL_TRI_BWD_PLAIN"],  # spatial polynomial backward: 126 monomials over flat tiles (round 1) instead of column strips
+    "bwd_s32": ["-DCURL_TRI_STRIP_STEPS_MAX=32"],  # rows per thread of the column strips capped at 32 (default 64)
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
