@@ -15,10 +15,25 @@ struct LossPx {
   float Lp, Lt;                           // clamped L of prediction and target (for MS-SSIM)
 };
 
+// cos and sin of float32(2*pi) * h for h in [0, 1] (model.py:70-75).  On gfx950: v_cos_f32 / v_sin_f32, which take their
+// argument in REVOLUTIONS -- over h = i / 2^22 they are within 1.3e-7 of the exact cos / sin(2 pi h), closer than the
+// reference's own float32 evaluation is (4.1e-7: its angle is rounded to float32 first), and within 4.6e-7 of the
+// reference's values (tools/ubench/sincos_probe.hip, profiles/r02/sincos_probe.log).  The library's sinf / cosf do a
+// full-range Payne-Hanek reduction: 100+ integer instructions and a branch each, 60 % of the loss kernel's instructions.
+CURL_HD void cos_sin_turns(float h, float& c, float& s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  c = __builtin_amdgcn_cosf(h), s = __builtin_amdgcn_sinf(h);
+#else
+  const float a = kTwoPi * h;
+  c = cosf(a), s = sinf(a);
+#endif
+}
+
 CURL_HD Px hsv_cone(Px hsv) {  // model.py:65-76 on clamp(rgb2hsv(x), 0, 1)
   float h = clamp01(hsv.c0), s = clamp01(hsv.c1), v = clamp01(hsv.c2);
-  float a = kTwoPi * h;
-  return Px{v * s * cosf(a), v * s * sinf(a), v};
+  float ca, sa;
+  cos_sin_turns(h, ca, sa);
+  return Px{v * s * ca, v * s * sa, v};
 }
 
 CURL_HD LossPx loss_terms(Px pred, Px tgt, float m) {
@@ -37,6 +52,63 @@ CURL_HD LossPx loss_terms(Px pred, Px tgt, float m) {
   Px cp = hsv_cone(rgb2hsv(p)), ct = hsv_cone(rgb2hsv(t));      // model.py:107-109
   o.hsv_l1 = (fabsf(cp.c0 - ct.c0) + fabsf(cp.c1 - ct.c1)) + fabsf(cp.c2 - ct.c2);
   return o;
+}
+
+// The same over the N pixels a lane owns, written as phases over 2N colours (N predictions, N targets): the converters'
+// transcendental runs are 6N long instead of 3, the cone's cos / sin run 4N (issue priority, curl_math.h).  sum[0..3] +=
+// the four terms over the N pixels; the arithmetic per pixel is loss_terms' (the single-pixel converters ARE the N = 1 forms).
+template <int N>
+CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m)[N], float (&sum)[4], float (&Lp)[N],
+                          float (&Lt)[N]) {
+  PxN<2 * N> x;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {  // model.py:91
+    x.c0[i] = pred.c0[i] * m[i], x.c1[i] = pred.c1[i] * m[i], x.c2[i] = pred.c2[i] * m[i];
+    x.c0[N + i] = tgt.c0[i] * m[i], x.c1[N + i] = tgt.c1[i] * m[i], x.c2[N + i] = tgt.c2[i] * m[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int j = N + i;
+    sum[0] += (fabsf(x.c0[i] - x.c0[j]) + fabsf(x.c1[i] - x.c1[j])) + fabsf(x.c2[i] - x.c2[j]);  // model.py:93
+    const float d = x.c0[i] * x.c0[j] + x.c1[i] * x.c1[j] + x.c2[i] * x.c2[j];
+    const float np = sqrtf(x.c0[i] * x.c0[i] + x.c1[i] * x.c1[i] + x.c2[i] * x.c2[i]);
+    const float nt = sqrtf(x.c0[j] * x.c0[j] + x.c1[j] * x.c1[j] + x.c2[j] * x.c2[j]);
+    sum[1] += d / (fmaxf(np, kCosEps) * fmaxf(nt, kCosEps));  // model.py:97
+  }
+  {
+    PxN<2 * N> lab = x;
+    rgb2lab_n<2 * N>(lab);  // model.py:100-101 (+ clamp, model.py:55)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int j = N + i;
+      const float l0 = clamp01(lab.c0[i]), l1 = clamp01(lab.c0[j]);
+      sum[2] += (fabsf(l0 - l1) + fabsf(clamp01(lab.c1[i]) - clamp01(lab.c1[j]))) + fabsf(clamp01(lab.c2[i]) - clamp01(lab.c2[j]));
+      Lp[i] = l0, Lt[i] = l1;
+    }
+  }
+  {
+    PxN<2 * N> hsv = x;
+    rgb2hsv_n<2 * N>(hsv);  // model.py:107-109
+    float ca[2 * N], sa[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) ca[i] = clamp01(hsv.c0[i]);
+    CURL_FENCE();
+    CURL_TRANS_BEGIN();
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) {
+      const float h = ca[i];
+      cos_sin_turns(h, ca[i], sa[i]);
+    }
+    CURL_TRANS_END();
+    CURL_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int j = N + i;
+      const float vi = clamp01(hsv.c2[i]), vj = clamp01(hsv.c2[j]);
+      const float ri = vi * clamp01(hsv.c1[i]), rj = vj * clamp01(hsv.c1[j]);
+      sum[3] += (fabsf(ri * ca[i] - rj * ca[j]) + fabsf(ri * sa[i] - rj * sa[j])) + fabsf(vi - vj);
+    }
+  }
 }
 
 CURL_HD float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }  // torch.sign / l1 backward
@@ -66,7 +138,8 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
   Px cp = hsv_cone(hp), ct = hsv_cone(rgb2hsv(t));
   float ge0 = w[3] * sign0(cp.c0 - ct.c0), ge1 = w[3] * sign0(cp.c1 - ct.c1), ge2 = w[3] * sign0(cp.c2 - ct.c2);
   float h = clamp01(hp.c0), s = clamp01(hp.c1), v = clamp01(hp.c2);
-  float a = kTwoPi * h, ca = cosf(a), sa = sinf(a);
+  float ca, sa;
+  cos_sin_turns(h, ca, sa);
   Px gh{kTwoPi * v * s * (ge1 * ca - ge0 * sa) * pass01(hp.c0), v * (ge0 * ca + ge1 * sa) * pass01(hp.c1),
         (s * (ge0 * ca + ge1 * sa) + ge2) * pass01(hp.c2)};
   Px g_hsv = rgb2hsv_bwd(p, gh);

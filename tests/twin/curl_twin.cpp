@@ -235,7 +235,26 @@ int twin_loss_terms(const float* pred, const float* tgt, const float* mask, doub
                     long HW) {
   for (int b = 0; b < B; ++b) {
     double acc[5] = {0, 0, 0, 0, 0};
-    for (long i = 0; i < HW; ++i) {
+    long i = 0;
+    for (; i + 4 <= HW; i += 4) {  // groups of four through the phase form the HIP kernel runs (loss_terms_n<4>)
+      const float* p = pred + (size_t)b * 3 * HW + i;
+      const float* t = tgt + (size_t)b * 3 * HW + i;
+      curlm::PxN<4> pp, tt;
+      float m[4], lp[4], lt[4], sum[4] = {0, 0, 0, 0};
+      for (int e = 0; e < 4; ++e) {
+        pp.c0[e] = p[e], pp.c1[e] = p[HW + e], pp.c2[e] = p[2 * HW + e];
+        tt.c0[e] = t[e], tt.c1[e] = t[HW + e], tt.c2[e] = t[2 * HW + e];
+        m[e] = mask ? mask[(size_t)b * HW + i + e] : 1.0f;
+        acc[4] += m[e];
+      }
+      curlm::loss_terms_n<4>(pp, tt, m, sum, lp, lt);
+      for (int k = 0; k < 4; ++k) acc[k] += sum[k];
+      for (int e = 0; e < 4; ++e) {
+        if (Lp) Lp[(size_t)b * HW + i + e] = lp[e];
+        if (Lt) Lt[(size_t)b * HW + i + e] = lt[e];
+      }
+    }
+    for (; i < HW; ++i) {
       const float* p = pred + (size_t)b * 3 * HW + i;
       const float* t = tgt + (size_t)b * 3 * HW + i;
       float m = mask ? mask[(size_t)b * HW + i] : 1.0f;

@@ -47,6 +47,7 @@ VARIANTS = {
     "poly_splat": ["-DCURL_POLY_SPLAT_FIRST"],  # the chains' first fma from a compiler-built {c, c} pair (v_mov per odd c)
     "poly_stage_r1": ["-DCURL_POLY_STAGE_GLOBAL"],  # row folds read global memory; pixel loads after the staging barrier
     "bwd_plain": ["-DCURL_TRI_BWD_PLAIN"],  # spatial polynomial backward: 126 monomials over flat tiles (round 1) instead of column strips
+    "loss_bwd_vec1": ["-DCURL_LOSS_BWD_VEC1"],  # CURLLoss terms backward at one pixel per lane (84 VGPRs) instead of four (186)
     "bwd_s32": ["-DCURL_TRI_STRIP_STEPS_MAX=32"],  # rows per thread of the column strips capped at 32 (default 64)
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
