@@ -48,3 +48,11 @@ for (B, H, W) in ((32, 1000, 1500), (32, 256, 256)):
         us = timeit(fn)
         print(f"{B}x{H}x{W}  {name:30s} {us:9.1f} us  {px * bpp / us / 1e6:7.2f} TB/s algorithmic ({bpp} B/px)  "
               f"= {px * bpp / us / 1e6 / 8.0:5.2f} of the HBM peak", flush=True)
+    # the byte edges (transpose.py + to_tensor / mul(255).byte()), stand-alone
+    u8 = (a * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    for name, fn, bpp in (("u8 HWC -> f32 CHW", lambda: ops.u8hwc_to_f32chw(u8), 15),
+                          ("f32 CHW -> u8 HWC", lambda: ops.f32chw_to_u8hwc(a), 15),
+                          ("compose white + u8 HWC (bool mask)", lambda: ops.compose_white_u8hwc(a, mask), 16)):
+        us = timeit(fn)
+        print(f"{B}x{H}x{W}  {name:30s} {us:9.1f} us  {px * bpp / us / 1e6:7.2f} TB/s algorithmic ({bpp} B/px)  "
+              f"= {px * bpp / us / 1e6 / 8.0:5.2f} of the HBM peak", flush=True)
