@@ -347,7 +347,11 @@ CURL_HD void rsub_run(float (&y)[M], float k, const float (&a)[M]) {
 __device__ __forceinline__ float select_le_hw(float x, float thr, float a, float b) {
   unsigned long long m;
   float r;
+#if defined(CURL_SELECT_VTHR)  // experiment build: the threshold in a VGPR, so that the compare reads no SGPR
+  asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(thr));
+#else
   asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(thr));
+#endif
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
   return r;
 }
