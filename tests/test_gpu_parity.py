@@ -1007,3 +1007,65 @@ def test_tuning_flags_do_not_change_results(ops, dev, shape):
                 assert torch.equal(ops.adjust_rgb(img, R, flags=fl)[0], rgb0), hex(fl)
     with pytest.raises(ValueError):
         ops.curl_layer_forward(img, mask, L, R, Hk, flags=3 << _lib.F_TUNE_BLOCK_SHIFT)
+
+
+def _misaligned(t):
+    """The same values in a tensor whose storage starts one element past an allocation boundary (4 bytes for float32, 1 byte
+    for uint8 / bool): contiguous, but not 16-byte aligned -> the kernels take their one-pixel-per-lane path."""
+    flat = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+    view = flat[1:].view(t.shape)
+    view.copy_(t)
+    assert view.data_ptr() % (16 if t.dtype == torch.float32 else 4) != 0 and view.is_contiguous()
+    return view
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 36, 40), (3, 37, 41), (1, 64, 256)])
+def test_vector_and_scalar_paths_of_the_f3_and_edge_kernels_agree(ops, dev, shape):
+    """PSNR, the CURLLoss terms (forward, backward) and the byte edges run 4 pixels per lane when the plane size is a multiple
+    of 4 and every base is aligned, one pixel per lane otherwise: both paths against each other (per-pixel outputs bit for
+    bit; sums to float32 rounding -- their blocks cover different pixel sets) and against the oracle / torch."""
+    import curl_oracle as O
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    a = torch.rand(B, 3, H, W, generator=g).to(dev)
+    b = (a + 0.1 * torch.randn(B, 3, H, W, generator=g).to(dev)).clamp(0, 1)
+    m = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+    w4 = torch.tensor([0.7, 1.3, 0.9, 1.1], device=dev)
+    gL = torch.rand(B, 1, H, W, generator=g).to(dev)
+    aligned = (H * W) % 4 == 0
+    variants = [(a, b, m, gL)]
+    if aligned:  # the same call through the other code path
+        variants.append((_misaligned(a), _misaligned(b), _misaligned(m), _misaligned(gL)))
+    res = []
+    for (x, y, mk, gl) in variants:
+        for mask in (mk, mk.float()):
+            sums, Lp, Lt = ops.loss_term_sums(x, y, mask)
+            res.append(dict(psnr=ops.psnr_per_image(x, y, mask), sums=sums, Lp=Lp, Lt=Lt,
+                            gb=ops.loss_terms_backward(x, y, mask, w4, gl), u8=ops.f32chw_to_u8hwc(x),
+                            white=ops.compose_white_u8hwc(x, mask)))
+    # against the oracle / torch
+    r0 = res[0]
+    for i in range(B):
+        want = O.psnr(a[i:i + 1].cpu(), b[i:i + 1].cpu(), m[i:i + 1].float().cpu())
+        assert abs(float(r0["psnr"][i]) - float(want)) < 1e-4
+    terms = O.curl_loss_terms(a.cpu(), b.cpu(), m.cpu())
+    got = r0["sums"].sum(0).cpu()
+    n = 3.0 * float(got[4])  # model.py:92: the sums are normalised by channels x unmasked pixels
+    assert abs(float(got[4]) - float(m.sum())) == 0.0
+    for k in (0, 2, 3):
+        assert abs(float(got[k]) / n - float(terms[k])) <= 3e-6, k
+    assert float((r0["Lp"].cpu() - terms[4]).abs().max()) <= 1e-6 and float((r0["Lt"].cpu() - terms[5]).abs().max()) <= 1e-6
+    assert torch.equal(r0["u8"].cpu(), (a.cpu() * 255).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1))
+    back = ops.u8hwc_to_f32chw(r0["u8"])
+    assert torch.equal(back.cpu(), r0["u8"].cpu().permute(0, 3, 1, 2).float() / 255)
+    if aligned:
+        assert torch.equal(ops.u8hwc_to_f32chw(_misaligned(r0["u8"])), back)
+    # the paths against each other
+    for r in res[1:]:
+        for k in ("Lp", "Lt", "u8", "white"):
+            assert torch.equal(r[k], r0[k]), k
+        # the gradient chains are compiled separately per path (other fma contractions): equal to float32 rounding
+        assert float((r["gb"] - r0["gb"]).abs().max() / r0["gb"].abs().max()) <= 2e-6
+        assert float((r["sums"] - r0["sums"]).abs().max() / r0["sums"].abs().max()) <= 1e-6
+        assert float((r["psnr"] - r0["psnr"]).abs().max()) <= 1e-4
