@@ -17,7 +17,17 @@ namespace curlm {
 #if defined(__HIP_DEVICE_COMPILE__)
 CURL_HD curl_f2 poly_fmav(curl_f2 a, curl_f2 v, curl_f2 q) { return __builtin_elementwise_fma(a, v, q); }
 #endif
-CURL_HD float poly_fmav(float a, float v, float q) { return fmaf(a, v, q); }
+// The scalar form on the device is an opaque v_fma_f32: left as fmaf, hipcc's SLP vectoriser packs the independent scalar
+// chains of a lane into v_pk_fma_f32 with a shuffle per operand and spills (poly_layer_kernel: 2 400 spilled registers).
+CURL_HD float poly_fmav(float a, float v, float q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(v), "v"(q));
+  return r;
+#else
+  return fmaf(a, v, q);
+#endif
+}
 
 // A coefficient as the evaluator's value type F.  seq(): from the consumption-order table; ref(): from the
 // reference-order table.  (Storing every coefficient twice, so that the packed type reads {c, c} as one 8-byte
@@ -31,9 +41,9 @@ struct PolyCoef<float> {
   static CURL_HD float ref(float x) { return x; }
   // the first fma of a Horner chain: its initial value is coefficient QA itself (consumption-order table)
   template <int QA, int QB>
-  static CURL_HD float fma_cc(const float* c, float v) { return fmaf(c[QA], v, c[QB]); }
+  static CURL_HD float fma_cc(const float* c, float v) { return poly_fmav(c[QA], v, c[QB]); }
   template <int QA>
-  static CURL_HD float fmav_c(const float* c, float v, float t) { return fmaf(c[QA], v, t); }
+  static CURL_HD float fmav_c(const float* c, float v, float t) { return poly_fmav(c[QA], v, t); }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <>
