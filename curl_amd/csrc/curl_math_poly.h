@@ -397,10 +397,46 @@ CURL_HD void trispace_bwd_px(Px in, float xw, float yh, const float* coef, Px go
     for (int c = 0; c < 3; ++c) vars[s][c] = v[s][c][0], gP[s][c] = g[s][c][0];
 }
 
+// Accumulator PAIRS for the coefficient gradients: on gfx950 one v_pk_fma_f32 per pair with the pixel's g as a broadcast
+// operand, the same monomial pairs for the three outputs.  (Left to hipcc's vectoriser over 3 x 35 floats, the second
+// output's pairs straddled the first's and the monomial products were packed too: 70 moves and shuffles per step next to 51
+// packed FMAs.)  NPAIR pairs hold 2 * NPAIR >= T monomials; the last half of an odd T is padding.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef curl_f2 grad_pair;
+#else
+struct grad_pair {
+  float x, y;
+};
+#endif
+template <int T, int NPAIR>
+CURL_HD void grad_pairs_accumulate(grad_pair (&acc)[3][NPAIR], float (&m)[2 * NPAIR], const float (&gP)[3]) {
+  static_assert(2 * NPAIR >= T && 2 * NPAIR - T <= 1, "pairs cover the monomials");
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int j = 0; j < T; ++j) asm volatile("" : "+v"(m[j]));  // scalar products, each in a register of its own choosing
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const curl_f2 g = {gP[o], gP[o]};
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+      const curl_f2 mk = {m[2 * k], m[2 * k + 1]};
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[o][k]) : "v"(g), "v"(mk));
+    }
+  }
+#else
+  for (int o = 0; o < 3; ++o)
+    for (int k = 0; k < NPAIR; ++k) {
+      acc[o][k].x = fmaf(gP[o], m[2 * k], acc[o][k].x);
+      acc[o][k].y = fmaf(gP[o], m[2 * k + 1], acc[o][k].y);
+    }
+#endif
+}
+CURL_HD float grad_pair_get(const grad_pair* acc, int j) { return (j & 1) ? acc[j >> 1].y : acc[j >> 1].x; }
+
 // acc[o][j] += gP[o] * m_{C*chunk + j}(v) for one pixel and one chunk of the monomials
 template <int V, int C>
-CURL_HD void coef_grad_accumulate(float (&acc)[3][PolyEval<V>::kChunk], const float (&v)[V], const float (&gP)[3]) {
-  constexpr int T = PolyEval<V>::kChunk;
+CURL_HD void coef_grad_accumulate(grad_pair (&acc)[3][(PolyEval<V>::kChunk + 1) / 2], const float (&v)[V], const float (&gP)[3]) {
+  constexpr int T = PolyEval<V>::kChunk, NPAIR = (T + 1) / 2;
   float pw[V][5];
 #pragma unroll
   for (int k = 0; k < V; ++k) {
@@ -410,29 +446,23 @@ CURL_HD void coef_grad_accumulate(float (&acc)[3][PolyEval<V>::kChunk], const fl
     pw[k][3] = pw[k][2] * v[k];
     pw[k][4] = pw[k][2] * pw[k][2];
   }
-  float m[T];
-  PolyEval<V>::template monomials<C>(m, pw);
+  float m[2 * NPAIR];
+  {
+    float mt[T];
+    PolyEval<V>::template monomials<C>(mt, pw);
 #pragma unroll
-  for (int o = 0; o < 3; ++o)
-#pragma unroll
-    for (int j = 0; j < T; ++j) acc[o][j] = fmaf(gP[o], m[j], acc[o][j]);
+    for (int j = 0; j < 2 * NPAIR; ++j) m[j] = j < T ? mt[j] : 0.0f;
+  }
+  grad_pairs_accumulate<T, NPAIR>(acc, m, gP);
 }
 
 // The same for the spatial polynomial with the COLUMN coordinate folded out (PolyFoldX, poly_horner.inc): a thread that
 // walks down one image column has one x, so it accumulates over the 70 monomials of (c0, c1, c2, y) -- chunk C of 35 --
 // and expands by the powers of x once at the end (coef_grad_expand_foldx): 35 monomials + 105 FMAs per pixel and chunk,
 // two chunks, instead of 42 + 126 and three.
-// The accumulators are PAIRS (35 monomials padded to 36): on gfx950 one v_pk_fma_f32 per pair, the same 18 monomial pairs
-// for the three outputs.  (Left to hipcc's vectoriser over 3 x 35 floats, the second output's pairs straddled the
-// first's and the monomial products were packed too: 70 moves and shuffles per step next to 51 packed FMAs.)
+// The accumulators are pairs (grad_pairs_accumulate above: 35 monomials padded to 36).
 constexpr int kFoldXPairs = 18;
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef curl_f2 foldx_pair;
-#else
-struct foldx_pair {
-  float x, y;
-};
-#endif
+typedef grad_pair foldx_pair;
 template <int C>
 CURL_HD void coef_grad_accumulate_foldx(foldx_pair (&acc)[3][kFoldXPairs], const float (&c)[3], float y, const float (&gP)[3]) {
   const float v[4] = {c[0], c[1], c[2], y};
@@ -452,25 +482,7 @@ CURL_HD void coef_grad_accumulate_foldx(foldx_pair (&acc)[3][kFoldXPairs], const
 #pragma unroll
     for (int j = 0; j < 2 * kFoldXPairs; ++j) m[j] = j < 35 ? m35[j] : 0.0f;
   }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-  for (int j = 0; j < 35; ++j) asm volatile("" : "+v"(m[j]));  // scalar products, each in a register of its own choosing
-#pragma unroll
-  for (int o = 0; o < 3; ++o) {
-    const curl_f2 g = {gP[o], gP[o]};
-#pragma unroll
-    for (int k = 0; k < kFoldXPairs; ++k) {
-      const curl_f2 mk = {m[2 * k], m[2 * k + 1]};
-      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[o][k]) : "v"(g), "v"(mk));
-    }
-  }
-#else
-  for (int o = 0; o < 3; ++o)
-    for (int k = 0; k < kFoldXPairs; ++k) {
-      acc[o][k].x = fmaf(gP[o], m[2 * k], acc[o][k].x);
-      acc[o][k].y = fmaf(gP[o], m[2 * k + 1], acc[o][k].y);
-    }
-#endif
+  grad_pairs_accumulate<35, kFoldXPairs>(acc, m, gP);
 }
 // e[i] = x^j_i * acc[m'_i] for slice S of chunk C's (monomial, x power) pairs; kPolyFoldXIndex[C][S][i] names the
 // reference coefficient each one is the gradient of

@@ -303,20 +303,24 @@ static void trispace_bwd_host(const float* img, const float* coeffs, const float
         float v[V];
         v[0] = vars[s][0], v[1] = vars[s][1], v[2] = vars[s][2];
         if (V == 5) v[V - 2] = xw, v[V - 1] = yh;
-        float a[3][T];
+        constexpr int NPAIR = (T + 1) / 2;
+        curlm::grad_pair a[3][NPAIR];
+        auto clear = [&]() {
+          for (int o = 0; o < 3; ++o) for (int k = 0; k < NPAIR; ++k) a[o][k] = curlm::grad_pair{0.0f, 0.0f};
+        };
         auto flush = [&](int c) {
           for (int o = 0; o < 3; ++o)
             for (int j = 0; j < T; ++j)
-              if (c * T + j < NC) acc[(s * 3 + o) * NC + c * T + j] += a[o][j];
+              if (c * T + j < NC) acc[(s * 3 + o) * NC + c * T + j] += curlm::grad_pair_get(a[o], j);
         };
-        for (int o = 0; o < 3; ++o) for (int j = 0; j < T; ++j) a[o][j] = 0.0f;
+        clear();
         coef_grad_accumulate<V, 0>(a, v, gP[s]);
         flush(0);
         if constexpr (PolyEval<V>::kChunks > 1) {
-          for (int o = 0; o < 3; ++o) for (int j = 0; j < T; ++j) a[o][j] = 0.0f;
+          clear();
           coef_grad_accumulate<V, 1>(a, v, gP[s]);
           flush(1);
-          for (int o = 0; o < 3; ++o) for (int j = 0; j < T; ++j) a[o][j] = 0.0f;
+          clear();
           coef_grad_accumulate<V, 2>(a, v, gP[s]);
           flush(2);
         }
