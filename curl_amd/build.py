@@ -13,14 +13,17 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include", "curl_hip.h")
 
 def _deps():
     """Everything the one translation unit reads: csrc/*.h|.hip|.inc, csrc/kernels/*.inc, the public header."""
-    out = [INCLUDE]
+    out = [INCLUDE, os.path.abspath(__file__)]  # this file too: a change of FLAGS rebuilds
     for d, _, files in os.walk(os.path.join(HERE, "csrc")):
         out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hip", ".inc"))]
     return out
 
 OUT = os.path.join(HERE, "lib", "libcurlhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-math-errno"]
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs independent scalar float chains into v_pk_*_f32 with a shuffle per operand
+# -- the packed forms this library wants are written out (curl_math_poly.h); without the pass the CURLLoss kernels are 5 %
+# faster and nothing is slower (profiles/r02/noslp_ab.log)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-math-errno", "-fno-slp-vectorize"]
 
 
 def build(force=False, verbose=False):

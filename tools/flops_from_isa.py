@@ -1,7 +1,7 @@
 """Static FLOP and VALU-issue counts of a kernel's hot basic block from hipcc's assembly (the numbers bench.py's
 `valu` rooflines use).
 
-    hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-math-errno -S --cuda-device-only -o /tmp/curl.s curl_amd/csrc/curl_kernels.hip
+    hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-math-errno -fno-slp-vectorize -S --cuda-device-only -o /tmp/curl.s curl_amd/csrc/curl_kernels.hip
     python tools/flops_from_isa.py /tmp/curl.s 'stream_kernelI7OpLayerLi4ELi1ELi1ELb1ELi0E' [px_per_lane=4]
 
 FLOPs per lane: v_pk_fma_f32 4, v_fma/v_fmac/v_fmamk/v_fmaak 2, v_pk_mul/v_pk_add 2, v_mul/v_add/v_sub/v_min/v_max/

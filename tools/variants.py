@@ -42,6 +42,7 @@ VARIANTS = {
     "nopk_t0": ["-DCURL_PRIO_TRANS=0"],
     "nopk_t3": ["-DCURL_PRIO_TRANS=3"],
     # polynomial model: its packed Horner code at raised priority too / the converters' helpers packed again
+    "slp": ["-fslp-vectorize"],  # WITH hipcc's SLP vectoriser (the product build disables it: it packs independent scalar chains into v_pk_* with shuffles)
     "sel_vthr": ["-DCURL_SELECT_VTHR"],  # thresholds of the selects in VGPRs (the compare then reads no SGPR)
     "sel_bitwise": ["-DCURL_SELECT_BITWISE"],
     "hue_bitwise": ["-DCURL_HUE_BITWISE"],  # only the hue terms' [c == max] factors in the sign-bit form  # threshold selects as sub / ashr / bitop3 (default: v_cmp + v_cndmask_e64)
