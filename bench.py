@@ -286,9 +286,35 @@ def end_to_end(ops, device, sets, masks, steps=5):
                 lay_ms.append(ev[1].elapsed_time(ev[2]))
     e, l = sorted(enc_ms)[len(enc_ms) // 2], sorted(lay_ms)[len(lay_ms) // 2]
     B = img.shape[0]
-    return {"model": "GCURLNet: efficientnetv2_rw_s encoder (random init, fp32, stock PyTorch-ROCm) on the 320x320 view + "
-                     "fused CURLLayer at 1500x1000", "batch": B, "encoder_ms": e, "curve_layer_ms": l,
-            "ms_per_batch": e + l, "images_per_s": B / ((e + l) * 1e-3), "curve_layer_share": l / (e + l)}
+    out = {"model": "GCURLNet: efficientnetv2_rw_s encoder (random init, fp32, stock PyTorch-ROCm) on the 320x320 view + "
+                    "fused CURLLayer at 1500x1000", "batch": B, "encoder_ms": e, "curve_layer_ms": l,
+           "ms_per_batch": e + l, "images_per_s": B / ((e + l) * 1e-3), "curve_layer_share": l / (e + l)}
+    # the fork's live model as infer.py:22-47 runs it: TriSpaceRegNet (efficientnetv2_rw_t backbone + the 1024-1024-512-512
+    # head) on the 320x320 view -> 3 x 3 x 126 coefficients -> the fused polynomial path on the full-resolution bytes
+    # (uint8 HWC in and out: to_tensor, white background and the truncating *255 inside the kernel)
+    from curl_amd import infer as infer_mod
+    tri = model.TriSpaceRegNet(spatial=True, is_train=False).to(device).eval()
+    u8 = sets[0][5]
+    ones = masks["ones"].float()
+    enc_ms, px_ms = [], []
+    with torch.no_grad():
+        for i in range(steps + 2):
+            ev[0].record()
+            small, msmall = infer_mod.encoder_view(img, ones)
+            coeffs = torch.stack(tri.generate_coefficients(small, msmall), 1)
+            ev[1].record()
+            ops.trispace_forward_u8hwc(u8, coeffs)
+            ev[2].record()
+            torch.cuda.synchronize(device)
+            if i >= 2:
+                enc_ms.append(ev[0].elapsed_time(ev[1]))
+                px_ms.append(ev[1].elapsed_time(ev[2]))
+    e2, p2 = sorted(enc_ms)[len(enc_ms) // 2], sorted(px_ms)[len(px_ms) // 2]
+    out["live_model"] = {"model": "TriSpaceRegNet (infer.py:22-47): efficientnetv2_rw_t backbone + head (random init, fp32, stock "
+                                  "PyTorch-ROCm) on the 320x320 view incl. the resize, + the fused polynomial path at 1500x1000 on "
+                                  "uint8 HWC in and out", "batch": B, "encoder_ms": e2, "per_pixel_path_ms": p2,
+                         "ms_per_batch": e2 + p2, "images_per_s": B / ((e2 + p2) * 1e-3), "per_pixel_share": p2 / (e2 + p2)}
+    return out
 
 
 def _cpu_model():
