@@ -424,3 +424,22 @@ def test_train_driver_reads_the_reference_folder_layout(dev, tmp_path):
                       "--crop", "64", "--batch_size", "2", "--width", "0.25", "--log_dirpath", str(tmp_path / "inf")])
     assert inf["mode"] == "inference" and inf["images"] == 3 and np.isfinite(inf["test_psnr"])
     assert sorted(p.name for p in (tmp_path / "inf" / "test" / "1").glob("*.png")) == ["10.png", "11.png", "9.png"]
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 1, 70), (2, 3, 64), (1, 17, 65), (1, 5, 129), (1, 33, 300), (1, 100, 7),
+                                   (1, 2, 1025)])
+def test_trispace_backward_edge_geometries_vs_twin(ops, dev, twin, shape):
+    """The spatial backward's column strips at the edges of their geometry -- one pixel, one row, one column block exactly
+    full / one lane over, 64- / 128- / 256-column blocks with ragged tails, more row phases than rows, five column blocks --
+    against the host twin of the same arithmetic (which is checked against the oracle's autograd in tests/test_poly.py)."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    img = torch.rand(B, 3, H, W, generator=g)
+    coeffs = torch.randn(B, 3, 3, 126, generator=g) * 0.3
+    w = torch.randn(B, 3, H, W, generator=g)
+    want = twin.trispace_bwd(img.numpy(), coeffs.numpy(), w.numpy(), False)
+    got = ops.trispace_backward(img.to(dev), coeffs.to(dev), w.to(dev))
+    assert rel(got, want) <= 2e-5
+    want35 = twin.trispace_bwd(img.numpy(), coeffs[..., :35].contiguous().numpy(), w.numpy(), False)
+    got35 = ops.trispace_backward(img.to(dev), coeffs[..., :35].contiguous().to(dev), w.to(dev))
+    assert rel(got35, want35) <= 2e-5
