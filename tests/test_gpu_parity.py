@@ -1069,3 +1069,19 @@ def test_vector_and_scalar_paths_of_the_f3_and_edge_kernels_agree(ops, dev, shap
         assert float((r["gb"] - r0["gb"]).abs().max() / r0["gb"].abs().max()) <= 2e-6
         assert float((r["sums"] - r0["sums"]).abs().max() / r0["sums"].abs().max()) <= 1e-6
         assert float((r["psnr"] - r0["psnr"]).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvar,shape", [(5, (2, 36, 40)), (5, (1, 37, 41)), (3, (2, 20, 64)), (3, (1, 1, 1)), (5, (1, 3, 1030))])
+def test_poly_layer_paths_vs_twin(ops, dev, twin, nvar, shape):
+    """The stand-alone polynomial layer: 4 scalar Horner chains per lane when planes are 4-pixel multiples and aligned, one
+    otherwise -- both against the host twin of the same arithmetic (bit for bit between the two GPU paths)."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(nvar * 100 + H + W)
+    x = torch.rand(B, nvar, H, W, generator=g)
+    c = torch.randn(B, 3, 126 if nvar == 5 else 35, generator=g) * 0.3
+    want = twin.poly_layer(x.numpy(), c.numpy())
+    got = ops.poly_layer(x.to(dev), c.to(dev))
+    assert max_err(N(got), want) <= 3e-6
+    if (H * W) % 4 == 0:
+        assert torch.equal(ops.poly_layer(_misaligned(x.to(dev)), c.to(dev)), got)
