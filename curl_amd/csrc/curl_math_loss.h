@@ -10,6 +10,17 @@ namespace curlm {
 constexpr float kTwoPi = (float)(2 * 3.141592653589793);  // 2*math.pi as float32 (model.py:70)
 constexpr float kCosEps = 1e-8f;                          // torch cosine_similarity eps
 
+// sqrt of the cosine term's squared norms.  Device: v_sqrt_f32 (1 ulp) -- the correctly rounded sqrtf expands to a scaled
+// Newton sequence with two `v_cndmask ..., vcc` (23 cycles each) per root; a relative 6e-8 on a cosine in
+// [-1, 1] is below what the reference's own float32 sums carry.  The quotient likewise: v_rcp_f32 + multiply.
+CURL_HD float loss_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+
 struct LossPx {
   float rgb_l1, cos_sim, lab_l1, hsv_l1;  // this pixel's contribution to the four sums
   float Lp, Lt;                           // clamped L of prediction and target (for MS-SSIM)
@@ -41,8 +52,8 @@ CURL_HD LossPx loss_terms(Px pred, Px tgt, float m) {
   LossPx o;
   o.rgb_l1 = (fabsf(p.c0 - t.c0) + fabsf(p.c1 - t.c1)) + fabsf(p.c2 - t.c2);  // model.py:93
   float d = p.c0 * t.c0 + p.c1 * t.c1 + p.c2 * t.c2;
-  float np = sqrtf(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = sqrtf(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
-  o.cos_sim = d / (fmaxf(np, kCosEps) * fmaxf(nt, kCosEps));  // model.py:97
+  float np = loss_sqrt(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = loss_sqrt(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
+  o.cos_sim = d * hw_rcp(fmaxf(np, kCosEps) * fmaxf(nt, kCosEps));  // model.py:97
   Px lp = rgb2lab(p), lt = rgb2lab(t);                          // model.py:100-101 (+ clamp, model.py:55)
   lp = Px{clamp01(lp.c0), clamp01(lp.c1), clamp01(lp.c2)};
   lt = Px{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
@@ -71,9 +82,9 @@ CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m
     const int j = N + i;
     sum[0] += (fabsf(x.c0[i] - x.c0[j]) + fabsf(x.c1[i] - x.c1[j])) + fabsf(x.c2[i] - x.c2[j]);  // model.py:93
     const float d = x.c0[i] * x.c0[j] + x.c1[i] * x.c1[j] + x.c2[i] * x.c2[j];
-    const float np = sqrtf(x.c0[i] * x.c0[i] + x.c1[i] * x.c1[i] + x.c2[i] * x.c2[i]);
-    const float nt = sqrtf(x.c0[j] * x.c0[j] + x.c1[j] * x.c1[j] + x.c2[j] * x.c2[j]);
-    sum[1] += d / (fmaxf(np, kCosEps) * fmaxf(nt, kCosEps));  // model.py:97
+    const float np = loss_sqrt(x.c0[i] * x.c0[i] + x.c1[i] * x.c1[i] + x.c2[i] * x.c2[i]);
+    const float nt = loss_sqrt(x.c0[j] * x.c0[j] + x.c1[j] * x.c1[j] + x.c2[j] * x.c2[j]);
+    sum[1] += d * hw_rcp(fmaxf(np, kCosEps) * fmaxf(nt, kCosEps));  // model.py:97
   }
   {
     PxN<2 * N> lab = x;
@@ -111,7 +122,17 @@ CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m
   }
 }
 
-CURL_HD float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }  // torch.sign / l1 backward
+// torch.sign (the L1 terms' backward): -1, 0, +1.  Device: two exact scalings by 2^100 take every nonzero float32 past +-1
+// (the smallest denormal: 2^-149 * 2^200 = 2^51; an overflow to +-inf is fine), then a median with -1 and +1 -- three plain
+// instructions instead of two compare + `v_cndmask ..., vcc` pairs.
+CURL_HD float sign0(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float big = 0x1p100f;
+  return __builtin_amdgcn_fmed3f((x * big) * big, -1.0f, 1.0f);
+#else
+  return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+#endif
+}
 
 // d(sum_k w[k] * term_k + gLp * Lp) / d pred for one pixel; w = weights of (rgb_l1, cos_sim, lab_l1, hsv_l1).
 CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float gLp) {
@@ -120,10 +141,11 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
   Px g{w[0] * sign0(p.c0 - t.c0), w[0] * sign0(p.c1 - t.c1), w[0] * sign0(p.c2 - t.c2)};
   // cosine similarity: c = d / (max(np,eps) max(nt,eps))
   float d = p.c0 * t.c0 + p.c1 * t.c1 + p.c2 * t.c2;
-  float np = sqrtf(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = sqrtf(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
+  float np = loss_sqrt(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = loss_sqrt(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
   float npc = fmaxf(np, kCosEps), ntc = fmaxf(nt, kCosEps);
-  float inv = 1.0f / (npc * ntc);
-  float k = (np > kCosEps) ? d * inv / (npc * np) : 0.0f;  // d/dp of 1/max(np,eps) is -p/np^3-ish only when np > eps
+  float inv = hw_rcp(npc * ntc);
+  // d/dp of 1/max(np,eps) is -p/np^3-ish only when np > eps (sign-bit mask of eps - np; np = 0 gives 0 * inf masked to 0)
+  float k = keep_if(neg_mask(kCosEps - np), d * inv * hw_rcp(npc * fmaxf(np, kCosEps)));
   g.c0 += w[1] * (t.c0 * inv - k * p.c0);
   g.c1 += w[1] * (t.c1 * inv - k * p.c1);
   g.c2 += w[1] * (t.c2 * inv - k * p.c2);
