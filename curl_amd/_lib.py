@@ -40,6 +40,7 @@ SIGNATURES = {
     "curl_rgb2hsv_f32": (_i, [_c_f, _c_f, _i, _i, _i, _u, _c_f]),
     "curl_hsv2rgb_f32": (_i, [_c_f, _c_f, _i, _i, _i, _u, _c_f]),
     "curl_lab_stage_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
+    "curl_hsv_stage_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _i, _u, _c_f]),
     "curl_layer_fwd_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz,
                                 _i, _i, _i, _i, _i, _i, _u, _c_f]),
     "curl_layer_fwd_slab_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz,

@@ -774,6 +774,31 @@ CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
 // what model.py:154-157 yields where the mask is 0: lab2rgb(0,0,0), the same colour for every such pixel
 CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }
 
+// model.py:163-169 as a stage of its own: rgb2hsv -> adjust_hsv -> *mask -> hsv2rgb (the layer's RGB residual).
+// The input is whatever the caller hands over (not known to be in [0,1]): the 1e-9 floors of colors.py:205,240 and the
+// refined reciprocal stay.  adjust_hsv4 clamps h, s, v to [0,1]; times a BINARY mask they are still there, so hsv2rgb's
+// input clamps go (UNIT), and hsv2rgb(0,0,0) = (0,0,0): a masked-out pixel is exactly 0, which the final `* m` yields.
+template <bool BINARY, int N>
+CURL_HD void hsv_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
+  rgb2hsv_n<N>(p);  // model.py:163
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Px h = adjust_hsv4(Px{p.c0[i], p.c1[i], p.c2[i]}, k[0], k[1], k[2], k[3]);  // model.py:165
+    if (!BINARY) {                                                              // model.py:166
+      h.c0 *= m[i];
+      h.c1 *= m[i];
+      h.c2 *= m[i];
+    }
+    Px o = hsv2rgb<BINARY>(h);  // model.py:169
+    if (BINARY) {               // m in {0, 1}: hsv2rgb(hsv * 0) == 0 == hsv2rgb(hsv) * 0
+      o.c0 *= m[i];
+      o.c1 *= m[i];
+      o.c2 *= m[i];
+    }
+    p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
+  }
+}
+
 // model.py:137-176 minus the dead `feat` lines.  For a BINARY mask every intermediate `* mask`
 // (model.py:154,160,166) is the identity where m == 1, and where m == 0 the result is 0 whatever the
 // intermediates were (every stage maps finite values to finite values and model.py:170 ends in `* mask`),
@@ -815,6 +840,13 @@ CURL_HD Px lab_stage(Px in, float m, const Affine* k) {
   PxN<1> q{{in.c0}, {in.c1}, {in.c2}};
   const float mm[1] = {m};
   lab_stage_n<BINARY, 1>(q, mm, k);
+  return Px{q.c0[0], q.c1[0], q.c2[0]};
+}
+template <bool BINARY>
+CURL_HD Px hsv_stage(Px in, float m, const Affine* k) {
+  PxN<1> q{{in.c0}, {in.c1}, {in.c2}};
+  const float mm[1] = {m};
+  hsv_stage_n<BINARY, 1>(q, mm, k);
   return Px{q.c0[0], q.c1[0], q.c2[0]};
 }
 template <bool BINARY>

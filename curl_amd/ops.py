@@ -72,11 +72,11 @@ def _one_device(fn):
     return wrapper
 
 
-def _coeffs32(coeffs):
-    """float32, contiguous, and 8-byte aligned (the kernels copy the table into LDS as 8-byte pairs; a view that starts
-    at an odd float of its storage is copied)."""
+def _coeffs32(coeffs, pairs=True):
+    """float32 and contiguous; pairs=True (the spatial 126-coefficient tables, which the kernels copy into LDS as 8-byte
+    pairs): also 8-byte aligned -- a view that starts at an odd float of its storage is copied."""
     c = coeffs.to(torch.float32).contiguous()
-    return c.clone() if c.data_ptr() % 8 else c
+    return c.clone() if pairs and c.data_ptr() % 8 else c
 
 
 def _check_out(out, img):
@@ -272,6 +272,24 @@ def lab_stage(img, mask, L, flags=0, out=None):
 
 @_one_device
 @_empty_ok(mask_arg=0)
+def hsv_stage(img, mask, H, flags=0, out=None):
+    """RGB -> HSV -> 4 curves -> *mask -> RGB in one pass (model.py:163-169): the layer's RGB residual. -> (rgb, reg_hsv)."""
+    lib = _lib.load()
+    img = _image(img)
+    B, _, Hh, W = img.shape
+    Hc, Kh = _knots(H, "H", 4, B)
+    m, kind = _mask(mask, img)
+    out = torch.empty_like(img) if out is None else _check_out(out, img)
+    reg = torch.empty(B, dtype=torch.float32, device=img.device)
+    ws, nbytes = _workspace(B, 4 * Kh, img.device)
+    rc = lib.curl_hsv_stage_f32(img.data_ptr(), _ptr(m), kind, Hc.data_ptr(), out.data_ptr(), reg.data_ptr(),
+                                ws.data_ptr(), nbytes, B, Hh, W, Kh, flags, _stream(img))
+    _lib.check(rc, "curl_hsv_stage_f32")
+    return out, reg
+
+
+@_one_device
+@_empty_ok(mask_arg=0)
 def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     """CURLLayer.forward (model.py:137-176) in one pass over the pixels. -> (img, reg[B]).
     L [B,3*Kl], R [B,3*Kr], H [B,4*Kh] are the already-sliced raw knots."""
@@ -333,7 +351,7 @@ def trispace_forward_rows(img, coeffs, rows, out, residual_only=False):
     _need_device(coeffs, "coeffs")
     if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
         raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
-    c = _coeffs32(coeffs)
+    c = _coeffs32(coeffs, pairs=coeffs.shape[3] == 126)
     out = _check_out(out, img)
     rc = lib.curl_trispace_fwd_slab_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, r0, n, c.shape[3],
                                         _lib.F_RESIDUAL_ONLY if residual_only else 0, _stream(img))
@@ -385,7 +403,7 @@ def trispace_forward(img, coeffs, residual_only=False, flags=0):
     _need_device(coeffs, "coeffs")
     if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
         raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
-    c = _coeffs32(coeffs)
+    c = _coeffs32(coeffs, pairs=coeffs.shape[3] == 126)
     out = torch.empty_like(img)
     rc = lib.curl_trispace_fwd_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, c.shape[3],
                                    flags | (_lib.F_RESIDUAL_ONLY if residual_only else 0), _stream(img))
@@ -399,7 +417,7 @@ def trispace_backward(img, coeffs, grad_out, residual_only=False):
     lib = _lib.load()
     img, grad_out = _image(img), _image(grad_out, "grad_out")
     B, _, H, W = img.shape
-    c = _coeffs32(coeffs)
+    c = _coeffs32(coeffs, pairs=coeffs.shape[3] == 126)
     nc = c.shape[3]
     g = torch.empty_like(c)
     nbytes = lib.curl_trispace_bwd_scratch_bytes(B, H, W, nc)
@@ -423,7 +441,7 @@ def poly_layer(img, coeffs):
     nc = 126 if V == 5 else 35
     if tuple(coeffs.shape) != (B, 3, nc):
         raise ValueError(f"coeffs must be [B={B},3,{nc}], got {tuple(coeffs.shape)}")
-    img, c = img.contiguous(), _coeffs32(coeffs)
+    img, c = img.contiguous(), _coeffs32(coeffs, pairs=False)  # poly_layer_kernel reads scalars
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
     _lib.check(lib.curl_poly_layer_f32(img.data_ptr(), c.data_ptr(), out.data_ptr(), B, H, W, V, _stream(img)),
                "curl_poly_layer_f32")
@@ -510,7 +528,7 @@ def trispace_forward_u8hwc(img_u8, coeffs, white_mask=None):
     _need_device(coeffs, "coeffs")
     if coeffs.dim() != 4 or coeffs.shape[:3] != (B, 3, 3) or coeffs.shape[3] not in (126, 35):
         raise ValueError(f"coeffs must be [B={B},3,3,126|35], got {tuple(coeffs.shape)}")
-    c = _coeffs32(coeffs)
+    c = _coeffs32(coeffs, pairs=coeffs.shape[3] == 126)
     wm = _white(white_mask, x)
     out = torch.empty_like(x)
     rc = lib.curl_trispace_fwd_u8hwc(x.data_ptr(), c.data_ptr(), _ptr(wm), out.data_ptr(), B, H, W, c.shape[3], 0,

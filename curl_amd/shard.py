@@ -26,7 +26,7 @@ def row_slab(height, rank, world):
 def broadcast_knots(knots, src=0, group=None):
     """Shared-encoder layout: rank `src` ran the encoder; everyone receives the raw knots [B,160].
     `knots` must be allocated with the right shape on every rank (contents ignored off `src`)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():  # a single-rank group still goes through the backend (RCCL)
         dist.broadcast(knots, src=src, group=group)
     return knots
 
@@ -34,7 +34,7 @@ def broadcast_knots(knots, src=0, group=None):
 def allgather_knots(local_knots, group=None):
     """Each rank encoded its image shard ([b_local,160]); returns the knots of the whole batch in rank order.
     Shards may differ by one row (image_shard); they are padded to the longest for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_knots
     world = dist.get_world_size(group)
     n_local = torch.tensor([local_knots.shape[0]], device=local_knots.device, dtype=torch.int64)
@@ -51,31 +51,35 @@ def allgather_knots(local_knots, group=None):
 
 def apply_row_slab(layer, img, mask, L, R, H, rank, world, out=None):
     """Split-pixels layout: apply the curve layer to this rank's rows of every image.  Returns (out, reg, (r0, r1))
-    with `out` a FULL-SIZE tensor (allocated here if not given) whose rows [r0, r1) hold the result.
+    with `out` a FULL-SIZE tensor (allocated here if not given) whose rows [r0, r1) hold the result; rows outside the
+    slab are NOT written (uninitialised memory unless the caller passed its own `out`).  `reg` is the same on every
+    rank, empty slabs included: it depends on the knots only.
 
-    On a HIP device the rows are processed in place through the stride-aware entry point
-    (ops.curl_layer_forward_rows -> curl_layer_fwd_slab_f32): no .contiguous() copy of the slab (a row slice of an
-    NCHW tensor is three separate chunks per image), 24-28 B/px like the whole-image call.  `layer` may be a
-    CURLLayer (its knot slicing is applied) or any callable (img, mask, L, R, H) -> (img, reg) for CPU rehearsals,
-    which takes the slice-and-copy route."""
+    `layer` is a CURLLayer (its knot slicing is applied) or any callable (img, mask, L, R, H) -> (img, reg).
+    * CURLLayer on a HIP device, nothing requiring a gradient: the rows are processed in place through the stride-aware
+      entry point (ops.curl_layer_forward_rows -> curl_layer_fwd_slab_f32) -- no .contiguous() copy of the slab (a row
+      slice of an NCHW tensor is three separate chunks per image), 24-28 B/px like the whole-image call.
+    * anything else (another callable, CPU rehearsals, or an input that requires grad -- the slab entry point has no
+      autograd node): the slice-and-copy route THROUGH `layer`, which stays differentiable."""
+    from .model import CURLLayer
     r0, r1 = row_slab(img.shape[2], rank, world)
     if out is None:
         out = torch.empty_like(img)
-    if r1 == r0:  # more ranks than rows: nothing to do here
-        reg = torch.zeros(img.shape[0], dtype=torch.float32, device=img.device)
+    needs_grad = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (img, L, R, H))
+    if r1 == r0:  # more ranks than rows: no pixels here, but the regulariser is still owed (knots only): 1-row stand-in
+        _, reg = layer(img[:, :, :1, :].contiguous(), None if mask is None else mask[:, :, :1, :].contiguous(), L, R, H)
         return out, reg, (r0, r1)
-    if img.is_cuda:
+    if img.is_cuda and isinstance(layer, CURLLayer) and not needs_grad:
         from . import ops
-        n = [getattr(layer, a, None) for a in ("num_lab_points", "num_rgb_points", "num_hsv_points")]
-        if None not in n:
-            L, R, H = L[:, :n[0]], R[:, :n[1]], H[:, :n[2]]  # model.py:153,159,165
-        flags = ops.F_PWL if getattr(layer, "paper_pwl", False) else 0  # CURLLayer(paper_pwl=True): the non-parity option
+        L, R, H = L[:, :layer.num_lab_points], R[:, :layer.num_rgb_points], H[:, :layer.num_hsv_points]  # model.py:153,159,165
+        flags = ops.F_PWL if layer.paper_pwl else 0  # CURLLayer(paper_pwl=True): the non-parity option
         _, reg = ops.curl_layer_forward_rows(img, mask, L, R, H, (r0, r1), out, flags=flags)
         return out, reg, (r0, r1)
     sub = img[:, :, r0:r1, :].contiguous()
     sub_mask = None if mask is None else mask[:, :, r0:r1, :].contiguous()
     o, reg = layer(sub, sub_mask, L, R, H)
-    out[:, :, r0:r1, :] = o
+    out[:, :, r0:r1, :] = o  # (autograd records the slice copy: `out` joins the graph when `o` carries one)
     return out, reg, (r0, r1)
 
 

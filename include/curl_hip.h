@@ -116,6 +116,15 @@ int curl_lab_stage_f32(const float* img, const void* mask, int mask_kind, const 
                        float* out, float* reg, void* workspace, size_t workspace_bytes,
                        int B, int H, int W, int Kl, unsigned flags, curl_stream_t stream);
 
+/* replaces: the third stage of CURLLayer.forward from RGB to its RGB residual, model.py:163-169
+ *           (rgb2hsv colors.py:195-242 -> adjust_hsv curves.py:41-87 -> *mask -> hsv2rgb colors.py:131-177) as ONE
+ *           pass over the pixels -- with curl_adjust_rgb_f32 and curl_lab_stage_f32 the "one fused kernel per colour
+ *           space" of the path.  rawH [B, 4*Kh].  reg [B] (nullable) is assigned reg_hsv.  Where a bool / uint8 mask is
+ *           0 the result is hsv2rgb(0,0,0) = 0.  flags: tuning bits only. */
+int curl_hsv_stage_f32(const float* img, const void* mask, int mask_kind, const float* rawH,
+                       float* out, float* reg, void* workspace, size_t workspace_bytes,
+                       int B, int H, int W, int Kh, unsigned flags, curl_stream_t stream);
+
 /* replaces: CURLLayer.forward(img, mask, L, R, H)  model.py:137-176, as ONE pass over the pixels.
  * rawL [B,3*Kl], rawR [B,3*Kr], rawH [B,4*Kh] (the slices L[:, :48], R[:, :48], H[:, :64] of
  * model.py:153,159,165, made contiguous by the caller).  reg [B] (nullable) is assigned

@@ -243,6 +243,15 @@ def lab_stage(img, mask, L, num_lab_points=48):
     return lab2rgb(lab), reg
 
 
+def hsv_stage(img, mask, H, num_hsv_points=64):
+    """Third stage of CURLLayer.forward from RGB to its RGB residual (model.py:163-169):
+    RGB -> HSV -> 4 curves -> * mask -> RGB.  Returns (residual_rgb, reg_hsv)."""
+    hsv = rgb2hsv(img)
+    hsv, reg = adjust_hsv(hsv, H[:, :num_hsv_points])
+    hsv = hsv * mask
+    return hsv2rgb(hsv), reg
+
+
 def curl_layer(img, mask, L, R, H, num_lab_points=48, num_rgb_points=48, num_hsv_points=64):
     """CURLLayer.forward (model.py:137-176) minus the dead `feat` lines."""
     rgb, reg_lab = lab_stage(img, mask, L, num_lab_points)
@@ -380,26 +389,29 @@ def deg4_mobile_poly_layer(img, coeffs):
     return (coeffs.reshape(img.shape[0], 3, 1, 1, 126) * torch.unsqueeze(terms, dim=1)).sum(dim=-1)
 
 
-def cat_coords(img, spatial=True):
-    """TriSpaceRegNet.cat_coords (model.py:487-497): append x/width and y/height planes."""
+def cat_coords(img, spatial=True, rows=None):
+    """TriSpaceRegNet.cat_coords (model.py:487-497): append x/width and y/height planes.
+    rows=(row0, H_full) (tests only): `img` is the band of rows [row0, row0 + img.shape[2]) of an image H_full rows
+    high -- the y plane then carries the FULL image's row / height, as the reference would compute for those rows."""
     if not spatial:
         return img
     B, _, H, W = img.shape
+    row0, H_full = (0, H) if rows is None else rows
     zeros = img[:, 0:1] * 0.0
     x = zeros + torch.arange(0, W).reshape(1, 1, 1, W) / W
-    y = zeros + torch.arange(0, H).reshape(1, 1, H, 1) / H
+    y = zeros + torch.arange(row0, row0 + H).reshape(1, 1, H, 1) / H_full
     return torch.cat([img, x, y], dim=1)
 
 
-def trispace_residual(img, R, L, H, spatial=True, mobile=True):
-    """TriSpaceRegNet.generate_residual (model.py:499-515).  R, L, H: [B,3,num_coeffs]."""
+def trispace_residual(img, R, L, H, spatial=True, mobile=True, rows=None):
+    """TriSpaceRegNet.generate_residual (model.py:499-515).  R, L, H: [B,3,num_coeffs].  rows: see cat_coords."""
     def poly(x, c):
         if spatial and mobile:
             return deg4_mobile_poly_layer(x, c)
         return channel_poly_layer(x, c, 4)
-    rgb_res = torch.sigmoid(poly(cat_coords(img, spatial), R))
-    lab_res = lab2rgb(torch.sigmoid(poly(cat_coords(rgb2lab(img), spatial), L)))
-    hsv_res = hsv2rgb(torch.sigmoid(poly(cat_coords(rgb2hsv(img), spatial), H)))
+    rgb_res = torch.sigmoid(poly(cat_coords(img, spatial, rows), R))
+    lab_res = lab2rgb(torch.sigmoid(poly(cat_coords(rgb2lab(img), spatial, rows), L)))
+    hsv_res = hsv2rgb(torch.sigmoid(poly(cat_coords(rgb2hsv(img), spatial, rows), H)))
     rgb_res = 2 * (rgb_res - 0.5)
     lab_res = 2 * (lab_res - 0.5)
     hsv_res = 2 * (hsv_res - 0.5)
@@ -491,3 +503,21 @@ def msssim(img1, img2, window_size=11, num_channel=3):
     w = weights.reshape(1, -1).to(img1.dtype)
     pow1, pow2 = mcs ** w, ssims ** w
     return torch.prod(pow1[:, :-1] * pow2[:, -1].reshape(-1, 1), dim=1)
+
+
+def input_sensitivity(img, mask, L, R, H, r64=None, h=1e-6):
+    """Conditioning of the chain at every pixel: max over the three input channels and both signs of
+    |d out / d in|, by finite differences of curl_layer evaluated in float64 -- how much model.py:137-176 amplifies a
+    rounding-sized perturbation there.  -> [B,H,W] float64.  The parity bound |HIP - ref| <= max(1e-5, 2e-6 * S) is
+    stated on it (tests/test_gpu_parity.py, __graft_entry__.smoke, bench.py accuracy)."""
+    img, mask, L, R, H = (t.double() for t in (img, mask, L, R, H))
+    if r64 is None:
+        r64, _ = curl_layer(img, mask, L, R, H)
+    S = torch.zeros(r64.shape[0], r64.shape[2], r64.shape[3], dtype=torch.float64)
+    for k in range(3):
+        for sgn in (1.0, -1.0):
+            p = img.clone()
+            p[:, k] += sgn * h
+            o, _ = curl_layer(p, mask, L, R, H)
+            S = torch.maximum(S, (o - r64).abs().amax(1) / h)
+    return S

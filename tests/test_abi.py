@@ -68,6 +68,9 @@ def test_argument_errors_are_codes_not_crashes():
     assert lib.curl_layer_fwd_f32(fake, None, 0, fake, fake, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 300, 16, 0,
                                   None) == -3  # K > CURL_MAX_KNOTS
     assert lib.curl_u8hwc_to_f32chw(fake, fake, 1, 4, 4, 2, None) == -2  # Cin
+    assert lib.curl_hsv_stage_f32(fake, None, 1, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 0, None) == -5  # mask NULL
+    assert lib.curl_hsv_stage_f32(fake, None, 0, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 0x2, None) == -6  # no PWL
+    assert lib.curl_hsv_stage_f32(fake, None, 0, fake, fake, None, fake, 8, 1, 4, 4, 16, 0, None) == -4  # workspace
     with pytest.raises(ValueError):
         _lib.check(-2, "x")
 
@@ -121,4 +124,8 @@ def test_polynomial_entries_refuse_a_misaligned_coefficient_table():
     assert lib.curl_trispace_fwd_u8hwc(fake, odd, None, fake, 1, 8, 8, 126, 0, None) == -2
     assert lib.curl_trispace_bwd_f32(fake, odd, fake, fake, fake, 1 << 30, 1, 8, 8, 126, 0, None) == -2
     src = open(os.path.join(ROOT, "curl_amd", "ops.py")).read()
-    assert src.count("coeffs.to(torch.float32).contiguous()") == 1 and src.count("_coeffs32(coeffs)") >= 5  # one helper, used everywhere
+    assert src.count("coeffs.to(torch.float32).contiguous()") == 1 and src.count("_coeffs32(coeffs") >= 5  # one helper, used everywhere
+    # only the 126-coefficient tables are read as pairs; an odd-float 35-coefficient table is not refused on
+    # alignment (with NULL images the first complaint is the image pointer, never "aligned")
+    three = ctypes.c_void_p(4096 + 2)
+    assert lib.curl_trispace_fwd_f32(fake, three, fake, 1, 8, 8, 35, 0, None) == -2 and b"4-byte" in lib.curl_last_error()

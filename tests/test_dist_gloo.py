@@ -62,3 +62,27 @@ def test_world_size_2_gloo(n_images):
     for r in range(world):
         ok_bcast, ok_gather, tmax, ok_slab, rows = ret[r]
         assert ok_bcast and ok_gather and ok_slab and tmax == 2.0 and rows == 10
+
+
+def test_apply_row_slab_keeps_gradients_and_the_regulariser():
+    """the slab route must stay differentiable through `layer` (the in-place HIP slab entry has no autograd
+    node and is taken only for a CURLLayer with nothing requiring grad), any callable must actually be called, and a
+    rank with an EMPTY slab (more ranks than rows) still returns the knots-only regulariser every other rank returns."""
+    from curl_amd import shard
+    torch.manual_seed(0)
+    img = torch.rand(2, 3, 3, 5)
+    L = torch.randn(2, 48, requires_grad=True)
+    calls = []
+
+    def layer(x, m, L, R, H):
+        calls.append(tuple(x.shape))
+        return x * L[:, :1].reshape(-1, 1, 1, 1), (L ** 2).sum(1)
+    out, reg, (r0, r1) = shard.apply_row_slab(layer, img, None, L, L, L, rank=1, world=3)
+    assert (r0, r1) == (1, 2) and calls == [(2, 3, 1, 5)]
+    (out[:, :, r0:r1].sum() + reg.sum()).backward()
+    want = img[:, :, 1:2].sum((1, 2, 3))
+    assert torch.allclose(L.grad[:, 0], want + 2 * L.detach()[:, 0]) and torch.allclose(L.grad[:, 1:], 2 * L.detach()[:, 1:])
+    # five ranks, three rows: ranks 3 and 4 own no row but owe the same regulariser
+    _, reg_full, _ = shard.apply_row_slab(layer, img, None, L, L, L, rank=0, world=5)
+    _, reg_empty, (a, b) = shard.apply_row_slab(layer, img, None, L, L, L, rank=4, world=5)
+    assert a == b and torch.equal(reg_empty, reg_full)

@@ -459,7 +459,12 @@ def test_gcurlnet_forward(dev):
         knots = net.predict_knots(img)
     L, R, H = O.split_knots(knots.cpu())
     ref, rreg = O.curl_layer(img.cpu(), mask.cpu().float(), L, R, H)
-    assert max_err(N(out), ref.numpy()) <= 2e-5
+    # north_star's 1e-5, except where the chain itself amplifies rounding noise: |err| <= max(1e-5, 2e-6 * S) per pixel
+    # with S the float64 chain's input sensitivity (the bound of test_fullsize_exception_set_is_pinned_by_conditioning)
+    S = O.input_sensitivity(img.cpu(), mask.cpu().float(), L, R, H)
+    d = (out.cpu().double() - ref.double()).abs().amax(1)
+    bound = torch.clamp(2e-6 * S, min=1e-5)
+    assert int((d > bound).sum()) == 0, (float((d / bound).max()), float(d.max()))
     np.testing.assert_allclose(N(reg), rreg.numpy(), rtol=1e-5)
 
 
@@ -471,8 +476,7 @@ def test_compose_white_background(ops, dev):
     for mask in (torch.rand(2, 1, 9, 13, generator=g) > 0.4, torch.rand(2, 1, 9, 13, generator=g)):
         want = np.stack([O.f32chw_to_u8hwc(O.white_background(x[b], mask[b].float())) for b in range(2)])
         got = ops.compose_white_u8hwc(x.to(dev), mask.to(dev))
-        assert (N(got).astype(int) - want.astype(int)).__abs__().max() <= 1  # fma vs mul+add at a truncation edge
-        assert (N(got) != want).mean() < 0.01
+        np.testing.assert_array_equal(N(got), want)  # x*m rounded, + (1-m) rounded: the reference's two eager ops
 
 
 def test_infer_cli_end_to_end(dev, tmp_path):
@@ -917,16 +921,7 @@ def test_row_slab_arguments_are_checked(ops, dev):
 
 
 def _input_sensitivity(O, img, mf, L, R, Hk, r64, h=1e-6):
-    """max over the three input channels and both signs of |d out / d in| per pixel, by finite differences of the
-    reference chain evaluated in float64: how much the chain amplifies a rounding-sized perturbation at this pixel."""
-    S = torch.zeros(r64.shape[0], r64.shape[2], r64.shape[3], dtype=torch.float64)
-    for k in range(3):
-        for sgn in (1.0, -1.0):
-            p = img.double().clone()
-            p[:, k] += sgn * h
-            o, _ = O.curl_layer(p, mf.double(), L.double(), R.double(), Hk.double())
-            S = torch.maximum(S, (o - r64).abs().amax(1) / h)
-    return S
+    return O.input_sensitivity(img, mf, L, R, Hk, r64=r64, h=h)
 
 
 def test_fullsize_exception_set_is_pinned_by_conditioning(ops, big):
@@ -966,6 +961,28 @@ def test_fullsize_exception_set_is_pinned_by_conditioning(ops, big):
         # the reference's own float32 evaluation needs the same allowance on this frame
         noise = (ref.double() - r64).abs().amax(1)
         assert float((noise > 1e-5).double().mean()) > 0.5 * float(over.double().mean())
+
+
+def test_wider_knots_sigma03_conditioning_bound(ops, dev):
+    """the 2e-6 * S constant of the pinned bound is a statement about the benchmark's knot spread (sigma 0.1).
+    At sigma 0.3 (the worst case of tools/parity_stress.py: seed 0, 512x768, no mask) the reference's OWN float32 result
+    needs 2.5e-6 * S against its float64 evaluation and the kernel 2.8e-6 * S against the reference: the constant that
+    holds for both is 3e-6, and the kernel stays within 25 % of the reference's own noise measured the same way."""
+    import curl_oracle as O
+    sigma, seed, H, W = 0.3, 0, 512, 768
+    g = torch.Generator().manual_seed(1000 * seed + int(sigma * 100))
+    img = torch.rand(1, 3, H, W, generator=g)
+    L, R, Hk = (torch.randn(1, n, generator=g) * sigma for n in (48, 48, 64))
+    mask = torch.ones(1, 1, H, W)
+    ref, _ = O.curl_layer(img, mask, L, R, Hk)
+    r64, _ = O.curl_layer(img.double(), mask.double(), L.double(), R.double(), Hk.double())
+    S = O.input_sensitivity(img, mask, L, R, Hk, r64=r64)
+    out, _ = ops.curl_layer_forward(img.to(dev), None, L.to(dev), R.to(dev), Hk.to(dev))
+    d = (out.cpu().double() - ref.double()).abs().amax(1)
+    noise = (ref.double() - r64).abs().amax(1)
+    bound = torch.clamp(3e-6 * S, min=1e-5)
+    assert int((d > bound).sum()) == 0, float((d / bound).max())
+    assert float((d / bound).max()) <= 1.25 * float((noise / bound).max()) + 0.05
 
 
 def test_config1_real_image_pixels_on_the_hip_path(ops, dev, golden):
@@ -1085,3 +1102,47 @@ def test_poly_layer_paths_vs_twin(ops, dev, twin, nvar, shape):
     assert max_err(N(got), want) <= 3e-6
     if (H * W) % 4 == 0:
         assert torch.equal(ops.poly_layer(_misaligned(x.to(dev)), c.to(dev)), got)
+
+
+# ------------------------------------------------------------------ fused HSV stage (model.py:163-169)
+@pytest.mark.parametrize("sig,tol", [("s01", 3e-6), ("s05", 1e-5)])
+def test_hsv_stage_golden(ops, dev, golden, sig, tol):
+    """curl_hsv_stage_f32 -- RGB -> HSV -> adjust_hsv -> *mask -> RGB in one pass -- against the reference's own
+    RGB2HSV / apply_curve x4 / HSV2RGB chained as model.py:163-169 chains them (make_golden_hsv_stage.py): unit-range,
+    8-bit-grid (exact channel ties, grey, black, white, primaries) and out-of-range inputs; no / bool / float masks."""
+    c = golden("hsv_stage")
+    H = T(c[sig + "_H"], dev)
+    for inn in ("img", "img8", "wide"):
+        for mk in ("ones", "holes", "disk", "soft"):
+            key = f"{sig}_{inn}_{mk}"
+            for m in _mask_variants(c, mk, dev):
+                out, reg = ops.hsv_stage(T(c[inn], dev), m, H)
+                assert max_err(N(out), c[key + "_out"]) <= tol, (key, None if m is None else m.dtype)
+                np.testing.assert_allclose(N(reg), c[key + "_reg"], rtol=2e-6)
+
+
+def test_hsv_stage_is_the_layers_third_stage(ops, dev, golden):
+    """The reference's chain fixture holds the HSV stage's INPUT (after_rgb_stage) for the all-ones mask and the layer's
+    output: clamp(img + hsv_stage(after_rgb_stage)) must be the layer (model.py:169-170), to 2e-6; shapes that take the
+    scalar path, in-place output and a masked-out wave (exactly 0 = hsv2rgb(0,0,0)) included."""
+    import curl_oracle as O
+    c = golden("chain")
+    H = T(c["s01_H"], dev)
+    res, reg = ops.hsv_stage(T(c["s01_img_ones_rgb_stage"], dev), None, H)
+    np.testing.assert_allclose(N(reg), c["s01_img_ones_reg_hsv"], rtol=2e-6)
+    assert max_err(N((T(c["img"], dev) + res).clamp(0, 1)), c["s01_img_ones_out"]) <= 2e-6
+    g = torch.Generator().manual_seed(5)
+    for B, Hh, W in ((1, 7, 9), (2, 33, 65), (1, 64, 1024)):
+        img = torch.rand(B, 3, Hh, W, generator=g) * 1.4 - 0.2
+        Hk = torch.randn(B, 64, generator=g) * 0.1
+        mask = torch.rand(B, 1, Hh, W, generator=g) > 0.3
+        mask[:, :, : Hh // 2] = False  # whole wavefronts masked out
+        want, wreg = O.hsv_stage(img, mask.float(), Hk)
+        for m in (mask.to(dev), mask.float().to(dev)):
+            x = img.to(dev)
+            got, reg = ops.hsv_stage(x, m, Hk.to(dev))
+            assert max_err(N(got), want.numpy()) <= 3e-6, (B, Hh, W, m.dtype)
+            assert (got[:, :, : Hh // 2] == 0).all()
+            ops.hsv_stage(x, m, Hk.to(dev), out=x)  # in place: every pixel is read before it is written
+            assert torch.equal(x, got)
+        np.testing.assert_allclose(N(reg), wreg.numpy(), rtol=2e-6)

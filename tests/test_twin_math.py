@@ -171,3 +171,24 @@ def test_layer_binary_form_on_ties_and_out_of_range_inputs(twin, seed):
 def test_coordinate_division_is_exact(twin):
     """cat_coords divides column by width (model.py:487-497); the kernels use a corrected reciprocal multiply."""
     assert twin.div_small_mismatches(8192) == 0
+
+
+@pytest.mark.parametrize("sig,tol", [("s01", 3e-6), ("s05", 1e-5)])
+def test_hsv_stage(twin, golden, sig, tol):
+    """hsv_stage_n (curl_math.h; model.py:163-169) on the host against the reference's outputs, every input kind (unit
+    range, 8-bit grid with channel ties, out of range) and mask kind; the binary-mask form is bit-identical."""
+    c = golden("hsv_stage")
+    H = c[sig + "_H"]
+    z = np.zeros((2, 48), np.float32)
+    for inn in ("img", "img8", "wide"):
+        for mk in ("ones", "holes", "disk", "soft"):
+            key = f"{sig}_{inn}_{mk}"
+            m = c["mask_" + mk].astype(np.float32)
+            out, reg = twin.layer(2, c[inn], m, z, z, H)
+            ref = c[key + "_out"]
+            d = np.abs(out.astype(np.float64) - ref)
+            assert d.max() <= tol, (key, d.max())  # exact channel ties (img8) included: tie terms are reproduced exactly
+            np.testing.assert_allclose(reg, c[key + "_reg"], rtol=2e-6)
+            if mk != "soft":
+                outb, _ = twin.layer(2, c[inn], m, z, z, H, binary=True)
+                assert np.array_equal(outb, out), key

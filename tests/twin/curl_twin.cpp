@@ -105,7 +105,7 @@ int twin_adjust(int ncurves, const float* img, const float* raw, float* out, flo
   return 0;
 }
 
-// stage 0: lab_stage (rawR/rawH ignored), 1: full layer.  mask: float [B,HW] or NULL.
+// stage 0: lab_stage (rawR/rawH ignored), 1: full layer, 2: hsv_stage (rawL/rawR ignored).  mask: float [B,HW] or NULL.
 // binary != 0: run the binary-mask specialisation (mask values must be 0 or 1), incl. the masked-out shortcut.
 int twin_layer(int stage, const float* img, const float* mask, const float* rawL, const float* rawR,
                const float* rawH, float* out, float* reg, int B, long HW, int Kl, int Kr, int Kh, int binary) {
@@ -113,11 +113,9 @@ int twin_layer(int stage, const float* img, const float* mask, const float* rawL
   for (int b = 0; b < B; ++b) {
     LayerCoef k;
     float rl = 0, rr = 0, rh = 0;
-    prep(rawL + (size_t)b * 3 * Kl, 3, Kl, k.lab, knots.data(), rl);
-    if (stage == 1) {
-      prep(rawR + (size_t)b * 3 * Kr, 3, Kr, k.rgb, knots.data(), rr);
-      prep(rawH + (size_t)b * 4 * Kh, 4, Kh, k.hsv, knots.data(), rh);
-    }
+    if (stage != 2) prep(rawL + (size_t)b * 3 * Kl, 3, Kl, k.lab, knots.data(), rl);
+    if (stage == 1) prep(rawR + (size_t)b * 3 * Kr, 3, Kr, k.rgb, knots.data(), rr);
+    if (stage >= 1) prep(rawH + (size_t)b * 4 * Kh, 4, Kh, k.hsv, knots.data(), rh);
     if (reg) reg[b] = (rl + rr) + rh;
     for (long i = 0; i < HW; ++i) {
       const float* p = img + (size_t)b * 3 * HW + i;
@@ -127,9 +125,9 @@ int twin_layer(int stage, const float* img, const float* mask, const float* rawL
       if (binary && m == 0.0f)
         y = stage == 0 ? lab_stage_masked_out() : Px{0.0f, 0.0f, 0.0f};
       else if (binary)
-        y = stage == 0 ? lab_stage<true>(x, m, k.lab) : curl_layer<true>(x, m, k);
+        y = stage == 0 ? lab_stage<true>(x, m, k.lab) : stage == 2 ? hsv_stage<true>(x, m, k.hsv) : curl_layer<true>(x, m, k);
       else
-        y = stage == 0 ? lab_stage<false>(x, m, k.lab) : curl_layer<false>(x, m, k);
+        y = stage == 0 ? lab_stage<false>(x, m, k.lab) : stage == 2 ? hsv_stage<false>(x, m, k.hsv) : curl_layer<false>(x, m, k);
       float* q = out + (size_t)b * 3 * HW + i;
       q[0] = y.c0, q[HW] = y.c1, q[2 * HW] = y.c2;
     }

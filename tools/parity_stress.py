@@ -29,13 +29,7 @@ for sigma in (0.1, 0.3, 0.5):
             else torch.rand(1, 1, H, W, generator=g)
         ref, rreg = O.curl_layer(img, mask, L, R, Hk)
         r64, _ = O.curl_layer(img.double(), mask.double(), L.double(), R.double(), Hk.double())
-        S = torch.zeros(1, H, W, dtype=torch.float64)
-        for k in range(3):
-            for sgn in (1e-6, -1e-6):
-                p = img.double().clone()
-                p[:, k] += sgn
-                o, _ = O.curl_layer(p, mask.double(), L.double(), R.double(), Hk.double())
-                S = torch.maximum(S, (o - r64).abs().amax(1) / 1e-6)
+        S = O.input_sensitivity(img, mask, L, R, Hk, r64=r64)
         m = None if kind == "none" else (mask.bool().to(dev) if kind == "bool" else mask.to(dev))
         out, reg = ops.curl_layer_forward(img.to(dev), m, L.to(dev), R.to(dev), Hk.to(dev))
         d = (out.cpu().double() - ref.double()).abs().amax(1)
