@@ -553,7 +553,14 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     nd[i] = fminf(r[i], fminf(g[i], b[i])) - mx[i];
     // 1/df and 1/mx from ONE reciprocal: q = 1/(df*mx), 1/df = q*mx, 1/mx = q*df (df*mx >= 1e-25, no underflow).
     // df == 0 gives inf/NaN; hue and saturation are masked to 0 below.
+    // UNIT: + 1e-30 keeps the reciprocal finite when df == 0, so that s = df * df * q is an exact 0 there without a mask
+    // (one fma instead of mul + and); df * mx >= 6e-8 * mx for any two distinct floats <= mx, so the addend changes q
+    // only where mx < 1e-20 -- and v = mx scales everything the HSV stage contributes to the output.
+#if defined(CURL_R2_HSV)
     rdm[i] = -nd[i] * mx[i];
+#else
+    rdm[i] = UNIT ? fmaf(-nd[i], mx[i], 1e-30f) : -nd[i] * mx[i];
+#endif
   }
   CURL_FENCE();
   CURL_TRANS_BEGIN();
@@ -583,7 +590,12 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // hue 1.0, not wrap to 0 -- the hue curves of adjust_hsv are not periodic)
     if (UNIT) h = fmaf(h, vconst((float)(1.0 / 6.0)), keep_if(neg_mask(h), 1.0f));
     else h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
-    float s = keep_if(live, nd[i] * (rdm[i] * nd[i]));  // colors.py:234-237: df/mx (0 when df == 0)
+    float s = nd[i] * (rdm[i] * nd[i]);  // colors.py:234-237: df/mx
+#if defined(CURL_R2_HSV)
+    s = keep_if(live, s);
+#else
+    if (!UNIT) s = keep_if(live, s);     // 0 when df == 0 (UNIT: nd == 0 and a finite q give exactly 0)
+#endif
     p.c0[i] = UNIT ? h : clampf(h, kHsvFloor, 1.0f);  // colors.py:240
     p.c1[i] = UNIT ? s : clampf(s, kHsvFloor, 1.0f);
     p.c2[i] = UNIT ? mx[i] : clampf(mx[i], kHsvFloor, 1.0f);
@@ -616,6 +628,7 @@ template <bool UNIT = false>  // UNIT: h, s, v already in [0,1] (straight out of
 CURL_HD Px hsv2rgb(Px p) {
   // colors.py:141-175 in sextant units: clamp(360h - a, 0, 60) * (d/60) == clamp(6h - a/60, 0, 1) * d,
   // so every ramp is one saturating add (v_add_f32 ... clamp) and the /60 disappears.
+#if defined(CURL_R2_HSV)  // A/B build (tools/variants.py): the round-2 form, two ramps and two fmas per channel
   float h = (UNIT ? p.c0 : clamp01(p.c0)) * vconst(6.0f), s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
   float q = v * (1.0f - s);
   float d = v - q;
@@ -623,6 +636,23 @@ CURL_HD Px hsv2rgb(Px p) {
   float r = fmaf(clamp01(h - 4.0f), d, fmaf(clamp01(h - 1.0f), -d, v));   // colors.py:144-150
   float g = fmaf(clamp01(h - 3.0f), -d, fmaf(clamp01(h), d, q));          // colors.py:153-159
   float b = fmaf(clamp01(h - 5.0f), -d, fmaf(clamp01(h - 2.0f), d, q));   // colors.py:163-168
+#else
+  // Each channel's two ramps are one trapezoid: for h6 = 6h in [0,6]
+  //   clamp(h6-1) - clamp(h6-4) = clamp(2 - |h6-3|),  clamp(h6) - clamp(h6-3) = clamp(2 - |h6-2|),
+  //   clamp(h6-2) - clamp(h6-5) = clamp(2 - |h6-4|)   (rise, plateau at 1, fall),
+  // so a channel is fma(h, 6, -c), 2 - |.| saturated (one VOP3 with abs and clamp), one fma: 3 instructions instead of 4,
+  // and d = v s, q = v - d replace 1-s, v(1-s), v-q: 11 instructions per pixel instead of 15 (the kernel runs at the
+  // board's power cap: instructions are joules).  Same piecewise-linear function, roundings of the same size.
+  const float hh = UNIT ? p.c0 : clamp01(p.c0), s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
+  const float d = v * s;   // v - p, p = v (1 - s): colors.py:142
+  const float q = v - d;
+  const float tr = clamp01(2.0f - fabsf(fmaf(hh, vconst(6.0f), -3.0f)));
+  const float tg = clamp01(2.0f - fabsf(fmaf(hh, vconst(6.0f), -2.0f)));
+  const float tb = clamp01(2.0f - fabsf(fmaf(hh, vconst(6.0f), -4.0f)));
+  float r = fmaf(tr, -d, v);   // colors.py:144-150
+  float g = fmaf(tg, d, q);    // colors.py:153-159
+  float b = fmaf(tb, d, q);    // colors.py:163-168
+#endif
   Px o;
   o.c0 = clamp01(r);
   o.c1 = clamp01(g);

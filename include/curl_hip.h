@@ -68,6 +68,10 @@ enum {
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */
 
+#define CURL_F_DIAG_SKIP_PREP 0x20000u /* DIAGNOSTICS ONLY (curl_layer_fwd_f32): the knot-prep launch is skipped and the
+                                         workspace is taken to hold an earlier call's result for the same knots; `reg`
+                                         is not written.  Measures what the prep launch + its kernel boundary cost. */
+
 int curl_version(void);
 /* Thread-local description of the last non-zero return on this thread ("" if none). */
 const char* curl_last_error(void);

@@ -108,13 +108,13 @@ def twin():
             return out, reg
 
         @staticmethod
-        def layer_bwd(img, mask, L, R, H, gout, greg):
+        def layer_bwd(img, mask, L, R, H, gout, greg, binary=False):
             img, mask, L, R, H, gout, greg = (f32(a) for a in (img, mask, L, R, H, gout, greg))
             B, _, Hh, W = img.shape
             gimg = np.empty_like(img)
             gL, gR, gH = np.empty_like(L), np.empty_like(R), np.empty_like(H)
             lib.twin_layer_bwd(P(img), P(mask), P(L), P(R), P(H), P(gout), P(greg), P(gimg), P(gL), P(gR), P(gH), B,
-                               ctypes.c_long(Hh * W), L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4)
+                               ctypes.c_long(Hh * W), L.shape[1] // 3, R.shape[1] // 3, H.shape[1] // 4, int(binary))
             return gimg, gL, gR, gH
 
         @staticmethod

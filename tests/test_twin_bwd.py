@@ -80,3 +80,27 @@ def test_regulariser_gradient_only(twin):
     for a, b in zip(got[1:], ref[1:]):
         assert rel(a, b.numpy()) <= 2e-5
     assert np.abs(got[0]).max() == 0
+
+
+@pytest.mark.parametrize("case", ["random", "grid8", "saturated"])
+def test_binary_mask_specialisation_equals_the_general_path(twin, case):
+    """bool / uint8 masks run curl_layer_bwd<BINARY>: no intermediate `* mask`, input clamps of the HSV stages known to
+    pass.  On 0/1 masks it must give what the general (float-mask) path gives -- the same values, pixel for pixel."""
+    g = torch.Generator().manual_seed({"random": 1, "grid8": 2, "saturated": 3}[case])
+    B, H, W = 2, 16, 24
+    img = torch.rand(B, 3, H, W, generator=g)
+    if case == "grid8":
+        img = torch.randint(0, 256, (B, 3, H, W), generator=g).float() / 255
+        img[:, 1, :4] = img[:, 0, :4]
+        img[:, 2, 4:8] = img[:, 1, 4:8]
+    if case == "saturated":
+        img = img * 1.6 - 0.3
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).float()
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (48, 48, 64))
+    w = torch.randn(B, 3, H, W, generator=g)
+    wr = torch.rand(B, generator=g)
+    a = twin.layer_bwd(img.numpy(), mask.numpy(), L.numpy(), R.numpy(), Hk.numpy(), w.numpy(), wr.numpy())
+    b = twin.layer_bwd(img.numpy(), mask.numpy(), L.numpy(), R.numpy(), Hk.numpy(), w.numpy(), wr.numpy(), binary=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert np.abs(a[0] * (1 - mask.numpy())).max() == 0

@@ -138,7 +138,7 @@ int twin_layer(int stage, const float* img, const float* mask, const float* rawL
 // Backward of twin_layer(stage=1): d loss/d img, d loss/d raw knots, given d loss/d out and d loss/d reg.
 int twin_layer_bwd(const float* img, const float* mask, const float* rawL, const float* rawR, const float* rawH,
                    const float* gout, const float* greg, float* gimg, float* gL, float* gR, float* gH, int B, long HW,
-                   int Kl, int Kr, int Kh) {
+                   int Kl, int Kr, int Kh, int binary) {
   std::vector<float> kl(3 * Kl), kr(3 * Kr), kh(4 * Kh);
   for (int b = 0; b < B; ++b) {
     LayerCoef k;
@@ -152,7 +152,8 @@ int twin_layer_bwd(const float* img, const float* mask, const float* rawL, const
       const float* g = gout + (size_t)b * 3 * HW + i;
       float m = mask ? mask[(size_t)b * HW + i] : 1.0f;
       float Pf[10] = {0}, Qf[10] = {0};
-      Px gi = curl_layer_bwd(Px{p[0], p[HW], p[2 * HW]}, m, k, Px{g[0], g[HW], g[2 * HW]}, Pf, Qf);
+      Px gi = binary ? curl_layer_bwd<true>(Px{p[0], p[HW], p[2 * HW]}, m, k, Px{g[0], g[HW], g[2 * HW]}, Pf, Qf)
+                     : curl_layer_bwd<false>(Px{p[0], p[HW], p[2 * HW]}, m, k, Px{g[0], g[HW], g[2 * HW]}, Pf, Qf);
       for (int c = 0; c < 10; ++c) P[c] += Pf[c], Q[c] += Qf[c];
       if (gimg) {
         float* q = gimg + (size_t)b * 3 * HW + i;

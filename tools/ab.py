@@ -56,6 +56,9 @@ def main():
             rc = lib.curl_layer_bwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
                                         gout.data_ptr(), 0, gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
                                         ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, 0, stream)
+        elif what == "hsv_stage":
+            rc = lib.curl_hsv_stage_f32(img.data_ptr(), mask.data_ptr(), 1, Hk.data_ptr(), out.data_ptr(), reg.data_ptr(),
+                                        ws.data_ptr(), nb, B, H, W, 16, flags, stream)
         elif what == "lab_stage":
             rc = lib.curl_lab_stage_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                         ws.data_ptr(), nb, B, H, W, 16, flags, stream)
@@ -80,6 +83,12 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 100)
+    # paired view: A and B of one round run within ~50 ms of each other, so the board's slow power / thermal drift (which
+    # moves a power-capped kernel by +-2 % over a session) cancels in the per-round difference
+    for d in sorted({v[1] for v in variants}):
+        diffs = sorted((b - a) / a * 100 for a, b in zip(times[("A", d)], times[("B", d)]))
+        print(f"{what:10s} B vs A {'VALU-only' if d else 'full     '} per-round difference: median {diffs[len(diffs)//2]:+.2f} %  "
+              f"quartiles {diffs[len(diffs)//4]:+.2f} .. {diffs[3*len(diffs)//4]:+.2f} %  ({len(diffs)} rounds)")
     for v in variants:
         t = sorted(times[v])
         print(f"{what:10s} {v[0]} ({os.path.basename(pa if v[0] == 'A' else pb)}) {'VALU-only' if v[1] else 'full     '} "

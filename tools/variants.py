@@ -51,6 +51,9 @@ VARIANTS = {
     "bwd_plain": ["-DCURL_TRI_BWD_PLAIN"],  # spatial polynomial backward: 126 monomials over flat tiles (round 1) instead of column strips
     "loss_bwd_vec1": ["-DCURL_LOSS_BWD_VEC1"],  # CURLLoss terms backward at one pixel per lane (84 VGPRs) instead of four (186)
     "bwd_s32": ["-DCURL_TRI_STRIP_STEPS_MAX=32"],  # rows per thread of the column strips capped at 32 (default 64)
+    "r2_hsv": ["-DCURL_R2_HSV"],  # round-2 HSV code: hsv2rgb as two saturated ramps + two fmas per channel (default: one trapezoid), s masked by df != 0
+    "bwd_interleave": ["-DCURL_BWD_INTERLEAVE"],  # layer backward: the lane's four pixels left to the compiler to interleave
+    "bwd_w4": ["-DCURL_BWD_WAVES=4"],  # layer backward held to 128 VGPRs (four waves per SIMD; 72 bytes of scratch per lane)
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
