@@ -77,11 +77,62 @@ WORKLOADS = {
                      flop_px=210.0),
     "trispace_u8": dict(desc="TriSpaceRegNet per-pixel path on interleaved uint8 HWC in and out (infer.py:35-47 fused)",
                         bpp=6.0, frag="OpTriSpace", mask=None, bound="valu", flop_px=1473.0),
+    # ---- BASELINE configs[4]'s kernels (the train step's custom HIP curve forward / backward and loss terms): VALU-bound,
+    # rooflined against the 157.3 TFLOP/s vector peak; flop_px from the kernels' ISA (tools/flops_from_isa.py --all)
+    "layer_bwd": dict(desc="curve-layer BACKWARD (curl_layer_bwd_f32: d img + d raw knots; autograd of model.py:137-176) on 8 x "
+                           "1500x1000 frames, bool mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu",
+                      flop_px=412.5, images=8),
+    "layer_bwd_crop": dict(desc="curve-layer backward on the training crop batch, 32 x 256x256 (main.py:88, data.py:86), bool "
+                                "mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu", flop_px=412.5,
+                           images=32, hw=(256, 256)),
+    "loss_fwd": dict(desc="CURLLoss pointwise terms forward (model.py:89-109: RGB L1, cosine, Lab L1, HSV-cone L1 of prediction "
+                          "and target + the two L planes), bool mask all ones", bpp=33.0, frag="loss_terms_kernel",
+                     mask="ones", bound="valu", flop_px=241.2),
+    "loss_bwd": dict(desc="CURLLoss pointwise terms backward (gradient w.r.t. the prediction)", bpp=41.0,
+                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=415.0),
+    "trispace_bwd": dict(desc="polynomial path backward (curl_trispace_bwd_f32: d loss / d 3x3x126 coefficients, main.py:287) "
+                              "on 8 x 1500x1000 frames: three kernels, 72 B/px of intermediates between the first two",
+                         bpp=24.0, frag="trispace_bwd", mask=None, bound="valu", flop_px=3120.0, images=8),
 }
+CONFIG5 = ("layer_bwd", "layer_bwd_crop", "loss_fwd", "loss_bwd", "trispace_bwd")
 
 
-def make_step(name, ops, masks):
+def workload_pixels(name, B):
+    w = WORKLOADS[name]
+    h, wd = w.get("hw", (H_IMG, W_IMG))
+    return min(w.get("images", B), B) * h * wd
+
+
+def make_step(name, ops, masks, sets=None):
     mask = masks.get(WORKLOADS[name]["mask"])
+    if name in CONFIG5:
+        w = WORKLOADS[name]
+        n = min(w.get("images", sets[0][0].shape[0]), sets[0][0].shape[0])
+        if "hw" in w:  # the training crop batch: its own small tensors
+            h, wd = w["hw"]
+            dev = sets[0][0].device
+            crops = [(s[0][:n, :, :h, :wd].contiguous(), s[1][:n], s[2][:n], s[3][:n]) for s in sets]
+            gout = torch.rand(n, 3, h, wd, device=dev)
+            m = torch.ones(n, 1, h, wd, dtype=torch.bool, device=dev)
+            turn = [0]
+
+            def crop_step(_s):
+                c = crops[turn[0] % len(crops)]
+                turn[0] += 1
+                return ops.curl_layer_backward(c[0], m, c[1], c[2], c[3], gout)
+            return crop_step
+        gout = sets[1 % len(sets)][0][:n]  # any resident float image serves as the incoming gradient
+        m = None if mask is None else mask[:n]
+        if name == "layer_bwd":
+            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gout)
+        if name == "trispace_bwd":
+            return lambda s: ops.trispace_backward(s[0][:n], s[4][:n], gout)
+        other = sets[1 % len(sets)][0]
+        if name == "loss_fwd":
+            return lambda s: ops.loss_term_sums(s[0], other, mask)
+        w4 = torch.ones(4, device=other.device)
+        gL = sets[0][0][:, :1].contiguous()
+        return lambda s: ops.loss_terms_backward(s[0], other, mask, w4, gL)
     if name in ("layer", "layer_disk"):
         return lambda s: ops.curl_layer_forward(s[0], mask, s[1], s[2], s[3])
     if name == "lab_stage":
@@ -321,6 +372,20 @@ def end_to_end(ops, device, sets, masks, steps=5):
     return out
 
 
+def train_step_record(device, rank, world, local, dist):
+    """BASELINE configs[4] in synthetic form ("report"): tools/train_step.py's measurement -- a
+    data-parallel train step of the curve model, 32 crops of 256x256 per GPU (main.py:88, data.py:86), encoder forward /
+    backward on stock PyTorch-ROCm, the fused HIP curve layer forward / backward, Adam; DDP over RCCL when world > 1 --
+    inside the bench line.  Every rank runs it (DDP needs them all); the dict is the same shape on each."""
+    import importlib.util
+    from types import SimpleNamespace
+    spec = importlib.util.spec_from_file_location("curl_train_step", os.path.join(ROOT, "tools", "train_step.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = SimpleNamespace(steps=20, warmup=8, size=256, batch=32, width=1.0)
+    return mod.run(args, device, rank, world, local, dist)
+
+
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -455,12 +520,12 @@ def main():
     sets = make_inputs(B, device, seed=rank)  # each rank synthesises ITS shard of the global batch
     masks = {"disk": disk_mask(B, H_IMG, W_IMG, device),
              "ones": torch.ones(B, 1, H_IMG, W_IMG, dtype=torch.bool, device=device), None: None}
-    npx_rank = B * H_IMG * W_IMG
 
     def measure(name, steps, warmup, cold=False):
         w = WORKLOADS[name]
         bpp = w["bpp"]
-        step = make_step(name, ops, masks)
+        step = make_step(name, ops, masks, sets)
+        npx_rank = workload_pixels(name, B)
         cold_us = cold_first_launch_us(step, sets, device) if cold else None
         wall, dev_ms, dev_ms_min = timed_run(step, sets, steps, warmup, dist, device)
         power = None
@@ -480,7 +545,8 @@ def main():
         mpix = world * npx_rank * steps / wall / 1e6
         gbps = npx_rank * bpp / (dev_ms * 1e-3) / 1e9
         tflops = npx_rank * w["flop_px"] / (dev_ms * 1e-3) / 1e12
-        traffic, traffic_src = load_traffic(w["frag"]) if B == 32 else (None, None)  # PMC pass was taken at bs32
+        # the PMC pass was taken at bs32 on the forward workloads
+        traffic, traffic_src = load_traffic(w["frag"]) if B == 32 and name not in CONFIG5 else (None, None)
         hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                "frac_of_measured_copy_ceiling_6290": gbps / 6290.0}
         valu = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,
@@ -504,6 +570,13 @@ def main():
             if name != args.workload:
                 # >= 200 timed launches (>= 40 ms) each: the Lab-stage figure the 70 % target is quoted on rides here
                 others.append(measure(name, max(200, args.steps // 2), max(3, args.warmup // 2)))
+
+    train = None
+    if not args.no_extras:
+        try:  # every rank takes part (DDP's all-reduce); context only, never at the expense of the line
+            train = train_step_record(device, rank, world, local, dist)
+        except Exception as e:
+            train = {"error": repr(e)}
 
     if rank == 0:
         line = {
@@ -533,6 +606,7 @@ def main():
                 line["end_to_end"] = end_to_end(ops, device, sets, masks)
             except Exception as e:  # context only: never at the expense of the line
                 line["end_to_end"] = {"error": repr(e)}
+            line["end_to_end"]["train_step"] = train
             if world == 1:
                 line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

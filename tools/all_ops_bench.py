@@ -58,6 +58,7 @@ ROWS = [  # name, images, bytes per pixel (read + written), fn
     ("adjust_hsv", B, 24, lambda i: ops.adjust_hsv(hsv, Hk)),
     ("lab_stage, no mask", B, 24, lambda i: ops.lab_stage(imgs[i & 1], None, L)),
     ("lab_stage, bool mask", B, 25, lambda i: ops.lab_stage(imgs[i & 1], mask_b, L)),
+    ("hsv_stage, bool mask", B, 25, lambda i: ops.hsv_stage(imgs[i & 1], mask_b, Hk)),
     ("layer, no mask", B, 24, lambda i: ops.curl_layer_forward(imgs[i & 1], None, L, R, Hk)),
     ("layer, bool mask", B, 25, lambda i: ops.curl_layer_forward(imgs[i & 1], mask_b, L, R, Hk)),
     ("layer, float mask", B, 28, lambda i: ops.curl_layer_forward(imgs[i & 1], mask_f, L, R, Hk)),

@@ -2,7 +2,9 @@
 `valu` rooflines use).
 
     hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-math-errno -fno-slp-vectorize -S --cuda-device-only -o /tmp/curl.s curl_amd/csrc/curl_kernels.hip
-    python tools/flops_from_isa.py /tmp/curl.s 'stream_kernelI7OpLayerLi4ELi1ELi1ELb1ELi0E' [px_per_lane=4]
+    python tools/flops_from_isa.py /tmp/curl.s 'stream_kernelI7OpLayerLi4ELi1ELi1ELb1ELi0E' [px_per_lane=4] [--all]
+(--all: sum every basic block instead of the largest one -- for straight-line kernels such as layer_bwd_kernel, whose
+ reduction epilogue is a block of its own)
 
 FLOPs per lane: v_pk_fma_f32 4, v_fma/v_fmac/v_fmamk/v_fmaak 2, v_pk_mul/v_pk_add 2, v_mul/v_add/v_sub/v_min/v_max/
 v_med3/v_min3/v_max3 (f32) 1, v_exp/v_log/v_rcp/v_rsq/v_sqrt 1; integer, bit, move, convert instructions 0.
@@ -41,9 +43,12 @@ def kernel_blocks(path, frag):
 
 def main():
     path, frag = sys.argv[1], sys.argv[2]
-    ppl = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    ppl = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("-") else 4
     blocks = kernel_blocks(path, frag)
-    hot = max(blocks, key=lambda b: sum(1 for i in b if i.startswith("v_")))
+    if "--all" in sys.argv:  # straight-line kernels (no loop): every block runs at most once per wave
+        hot = [i for b in blocks for i in b]
+    else:
+        hot = max(blocks, key=lambda b: sum(1 for i in b if i.startswith("v_")))
     valu = [i for i in hot if i.startswith("v_")]
     flops = 0
     for i in valu:
