@@ -55,10 +55,18 @@ static int hip_fail(hipError_t e, const char* where) {
 
 static inline unsigned ws_stride(int n_knots) { return WS_KNOTS + ((unsigned)(n_knots + 3) & ~3u); }
 
+// Knots per curve as the C ABI carries them (include/curl_hip.h, CURL_K_UNEVEN): K in the low 16 bits; the high 16 bits,
+// when non-zero, are the knot count of the segment's LAST curve -- what torch.chunk hands it when the parameter count does
+// not divide (curves.py:53,105,152).  Curve c of a segment of n curves starts c * K knots into it.
+#define KP_K(p) ((int)((unsigned)(p) & 0xffffu))
+#define KP_LAST(p) ((int)(((unsigned)(p) >> 16) ? ((unsigned)(p) >> 16) : ((unsigned)(p) & 0xffffu)))
+#define KP_TOTAL(p, n) (((n) - 1) * KP_K(p) + KP_LAST(p))
+#define KP_UNEVEN(p) (KP_LAST(p) != KP_K(p))
+
 struct PrepArgs {
   const float* raw[3];  // per segment: [B, ncurves*K] raw (pre-exp) parameters, NULL if absent
   int ncurves[3];
-  int K[3];
+  int K[3];  // packed (KP_*)
   float* ws;
   float* reg_out;  // nullable, [B], assigned
   unsigned stride;
@@ -74,12 +82,12 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
   int seg_off[4];
   seg_off[0] = 0;
 #pragma unroll
-  for (int s = 0; s < 3; ++s) seg_off[s + 1] = seg_off[s] + (a.raw[s] ? a.ncurves[s] * a.K[s] : 0);
+  for (int s = 0; s < 3; ++s) seg_off[s + 1] = seg_off[s] + (a.raw[s] ? KP_TOTAL(a.K[s], a.ncurves[s]) : 0);
   const int n_total = seg_off[3];
   for (int i = threadIdx.x; i < n_total; i += 256) {
     int s = (i >= seg_off[2]) ? 2 : (i >= seg_off[1]) ? 1 : 0;
     int local = i - seg_off[s];
-    int per_img = a.ncurves[s] * a.K[s];
+    int per_img = KP_TOTAL(a.K[s], a.ncurves[s]);
     float r = a.raw[s][(size_t)b * per_img + local];
     float c = (float)exp((double)r);  // curves.py:54,106,153
     sC[i] = c;
@@ -95,8 +103,9 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
   const int c = threadIdx.x;
   if (c < n_curves) {
     int s = (c >= curve0[2]) ? 2 : (c >= curve0[1]) ? 1 : 0;
-    int K = a.K[s];
-    const float* C = sC + seg_off[s] + (c - curve0[s]) * K;
+    const int local = c - curve0[s];
+    const int K = (local == a.ncurves[s] - 1) ? KP_LAST(a.K[s]) : KP_K(a.K[s]);  // torch.chunk: the last curve may be shorter
+    const float* C = sC + seg_off[s] + local * KP_K(a.K[s]);
     float ca, cb, creg;
     collapse_curve(C, K, ca, cb, creg);
     ws[WS_COEF + 2 * c] = ca;

@@ -778,6 +778,45 @@ CURL_HD float scale_pwl_pairs(float x, const float* tab, int K) {
   return fmaf(tab[2 * i + 1], frac, tab[2 * i]);
 }
 
+// curves.py:31-32 in torch's evaluation order (scale_exact) from the same interleaved table: C_0 at tab[0], slope_j at
+// tab[2 j + 1] -- the validation mode of the fused stages (CURL_F_EXACT_ORDER): every lane reads the same address
+// (broadcast), 4 instructions per term instead of one fma per curve
+CURL_HD float scale_exact_pairs(float x, const float* tab, int K) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const int n_terms = K - 2;
+  const float sx = (float)(K - 1) * x;
+  float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+  int j = 0;
+  for (; j + 16 <= n_terms;) {
+    for (int e = 0; e < 16; ++e, ++j) {
+      float t = sx - (float)j;
+      float p = tab[2 * j + 1] * t;
+      acc0 = acc0 + p;
+    }
+    acc1 = acc1 + acc0;
+    acc0 = 0.0f;
+    if ((j & 0xF0) == 0) {
+      acc2 = acc2 + acc1;
+      acc1 = 0.0f;
+    }
+  }
+  for (; j < n_terms; ++j) {
+    float t = sx - (float)j;
+    float p = tab[2 * j + 1] * t;
+    acc0 = acc0 + p;
+  }
+  acc0 = acc0 + acc1;
+  acc0 = acc0 + acc2;
+  return tab[0] + acc0;
+}
+// MODE 0: the paper's clamped interpolation (CURL_F_PWL); 1: the reference's sum, term by term (CURL_F_EXACT_ORDER)
+template <int MODE>
+CURL_HD float scale_tab(float x, const float* tab, int K) {
+  return MODE == 1 ? scale_exact_pairs(x, tab, K) : scale_pwl_pairs(x, tab, K);
+}
+
 struct LayerCoef {
   Affine lab[3], rgb[3], hsv[4];
 };

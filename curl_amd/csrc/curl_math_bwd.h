@@ -463,24 +463,27 @@ CURL_HD Px curl_layer_bwd(Px in, float m, const LayerCoef& k, Px gout, float* P,
 // ---- per image: (P, Q) of one curve + d loss / d reg  ->  gradient of that curve's RAW knots (pre-exp).
 // C = exp(raw) (already computed); scale = C0 + sum_{j<=K-3} slope_j (S x - j); reg = sum_j (slope_{j+1}-slope_j)^2.
 // Everything in float64: K is tiny and this runs once per curve per image.
-CURL_HD void knots_bwd(const float* C, int K, double P, double Q, double g_reg, float* g_raw) {
+// One knot of it (the kernel hands every (curve, knot) pair to a thread of its own: as one thread per curve the K-long
+// loop of float64 chains was ~10 us of every backward call).
+CURL_HD float knot_bwd(const float* C, int K, double P, double Q, double g_reg, int kk) {
   const double S = (double)(K - 1);
-  for (int kk = 0; kk < K; ++kk) {
-    // dL/dslope_j  (slope_j = C[j+1]-C[j], j = 0..K-2)
-    auto dslope = [&](int j) -> double {
-      if (j < 0 || j > K - 2) return 0.0;
-      double v = 0.0;
-      if (j <= K - 3) v += S * Q - (double)j * P;  // pixels
-      // regulariser: terms (slope_j - slope_{j-1})^2 and (slope_{j+1} - slope_j)^2
-      auto sl = [&](int i) { return (double)(C[i + 1] - C[i]); };
-      if (j >= 1) v += g_reg * 2.0 * (sl(j) - sl(j - 1));
-      if (j + 1 <= K - 2) v -= g_reg * 2.0 * (sl(j + 1) - sl(j));
-      return v;
-    };
-    double gC = dslope(kk - 1) - dslope(kk);
-    if (kk == 0) gC += P;  // the C0 term of the scale
-    g_raw[kk] = (float)(gC * (double)C[kk]);  // d exp(raw) = C
-  }
+  // dL/dslope_j  (slope_j = C[j+1]-C[j], j = 0..K-2)
+  auto dslope = [&](int j) -> double {
+    if (j < 0 || j > K - 2) return 0.0;
+    double v = 0.0;
+    if (j <= K - 3) v += S * Q - (double)j * P;  // pixels
+    // regulariser: terms (slope_j - slope_{j-1})^2 and (slope_{j+1} - slope_j)^2
+    auto sl = [&](int i) { return (double)(C[i + 1] - C[i]); };
+    if (j >= 1) v += g_reg * 2.0 * (sl(j) - sl(j - 1));
+    if (j + 1 <= K - 2) v -= g_reg * 2.0 * (sl(j + 1) - sl(j));
+    return v;
+  };
+  double gC = dslope(kk - 1) - dslope(kk);
+  if (kk == 0) gC += P;  // the C0 term of the scale
+  return (float)(gC * (double)C[kk]);  // d exp(raw) = C
+}
+CURL_HD void knots_bwd(const float* C, int K, double P, double Q, double g_reg, float* g_raw) {
+  for (int kk = 0; kk < K; ++kk) g_raw[kk] = knot_bwd(C, K, P, Q, g_reg, kk);
 }
 
 }  // namespace curlm

@@ -115,13 +115,16 @@ def _knots(t, name, ncurves, B):
     _need_device(t, name)
     if t.dim() != 2 or t.shape[0] != B:
         raise ValueError(f"{name} must be [B={B}, {ncurves}*K], got {tuple(t.shape)}")
-    if t.shape[1] % ncurves != 0:
-        # torch.chunk would hand the last curve fewer knots (curves.py:53,105,152); not supported
-        raise ValueError(f"{name}: {t.shape[1]} parameters do not split into {ncurves} equal curves")
-    K = t.shape[1] // ncurves
-    if K < 2 or K > _lib.MAX_KNOTS:
-        raise ValueError(f"{name}: {K} knots per curve; supported range is [2, {_lib.MAX_KNOTS}]")
-    return t.to(torch.float32).contiguous(), K
+    N = t.shape[1]
+    K = -(-N // ncurves)  # torch.chunk(P, n, dim=1): chunks of ceil(N / n) (curves.py:53,105,152) ...
+    if ncurves > 1 and -(-N // K) != ncurves:
+        # ... of which there may then be fewer than n: the reference's tuple unpacking fails on that
+        raise ValueError(f"{name}: torch.chunk splits {N} parameters into {-(-N // K)} chunks, not {ncurves} curves")
+    K_last = N - (ncurves - 1) * K  # ... and the last one holds the remainder
+    if K < 2 or K > _lib.MAX_KNOTS or K_last < 2:
+        raise ValueError(f"{name}: {K} knots per curve ({K_last} in the last); supported range is [2, {_lib.MAX_KNOTS}]")
+    # the C ABI's packed form (include/curl_hip.h CURL_K_UNEVEN): K, and the last curve's count in the high half if it differs
+    return t.to(torch.float32).contiguous(), (K if K_last == K else K | (K_last << 16))
 
 
 def _mask(mask, img):
@@ -184,7 +187,7 @@ def _adjust(fn_name, ncurves, img, raw, flags):  # noqa: E302
     rawc, K = _knots(raw, "knots", ncurves, B)
     out = torch.empty_like(img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
-    ws, nbytes = _workspace(B, ncurves * K, img.device)
+    ws, nbytes = _workspace(B, rawc.shape[1], img.device)
     rc = getattr(lib, fn_name)(img.data_ptr(), rawc.data_ptr(), out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes,
                                B, H, W, K, flags, _stream(img))
     _lib.check(rc, fn_name)
@@ -263,7 +266,7 @@ def lab_stage(img, mask, L, flags=0, out=None):
     m, kind = _mask(mask, img)
     out = torch.empty_like(img) if out is None else _check_out(out, img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
-    ws, nbytes = _workspace(B, 3 * Kl, img.device)
+    ws, nbytes = _workspace(B, Lc.shape[1], img.device)
     rc = lib.curl_lab_stage_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                 ws.data_ptr(), nbytes, B, H, W, Kl, flags, _stream(img))
     _lib.check(rc, "curl_lab_stage_f32")
@@ -281,7 +284,7 @@ def hsv_stage(img, mask, H, flags=0, out=None):
     m, kind = _mask(mask, img)
     out = torch.empty_like(img) if out is None else _check_out(out, img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
-    ws, nbytes = _workspace(B, 4 * Kh, img.device)
+    ws, nbytes = _workspace(B, Hc.shape[1], img.device)
     rc = lib.curl_hsv_stage_f32(img.data_ptr(), _ptr(m), kind, Hc.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                 ws.data_ptr(), nbytes, B, Hh, W, Kh, flags, _stream(img))
     _lib.check(rc, "curl_hsv_stage_f32")
@@ -302,7 +305,7 @@ def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
     m, kind = _mask(mask, img)
     out = torch.empty_like(img) if out is None else _check_out(out, img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
-    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
+    ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], img.device)
     rc = lib.curl_layer_fwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
                                 out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, Kl, Kr, Kh,
                                 flags, _stream(img))
@@ -332,7 +335,7 @@ def curl_layer_forward_rows(img, mask, L, R, H, rows, out, flags=0):
     m, kind = _mask(mask, img)
     out = _check_out(out, img)
     reg = torch.empty(B, dtype=torch.float32, device=img.device)
-    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
+    ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], img.device)
     rc = lib.curl_layer_fwd_slab_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
                                      out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, r0, n, Kl, Kr, Kh,
                                      flags, _stream(img))
@@ -380,7 +383,7 @@ def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_i
             raise ValueError("grad_reg must be [B]")
     g_img = torch.empty_like(img) if need_grad_img else None
     gL, gR, gH = torch.empty_like(Lc), torch.empty_like(Rc), torch.empty_like(Hc)
-    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, img.device)
+    ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], img.device)
     sbytes = lib.curl_layer_bwd_scratch_bytes(B, Hh, W)
     scratch = torch.empty(sbytes // 4, dtype=torch.float32, device=img.device)
     rc = lib.curl_layer_bwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
@@ -551,7 +554,7 @@ def curl_layer_forward_u8hwc(img_u8, mask, L, R, H, white_mask=None):
     wm = _white(white_mask, x)
     out = torch.empty_like(x)
     reg = torch.empty(B, dtype=torch.float32, device=x.device)
-    ws, nbytes = _workspace(B, 3 * Kl + 3 * Kr + 4 * Kh, x.device)
+    ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], x.device)
     rc = lib.curl_layer_fwd_u8hwc(x.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(), _ptr(wm),
                                   out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, Kl, Kr, Kh, 0,
                                   _stream(x))

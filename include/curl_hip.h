@@ -45,6 +45,11 @@ enum {
 };
 
 #define CURL_MAX_KNOTS 256
+/* Every `K` argument is the number of knots per curve.  torch.chunk(P, n, dim=1) of a parameter count that n does not
+ * divide hands the first n-1 curves K = ceil(N/n) knots and the LAST one fewer (curves.py:53,105,152): pass
+ * CURL_K_UNEVEN(K, K_last) for that segment (raw pointer: [B, (n-1)*K + K_last]).  Supported by the default (affine)
+ * forward forms and the backward; CURL_F_EXACT_ORDER / CURL_F_PWL and curl_apply_curve_f32 take a plain K. */
+#define CURL_K_UNEVEN(K, K_last) ((int)((unsigned)(K) | ((unsigned)(K_last) << 16)))
 
 /* mask_kind */
 #define CURL_MASK_NONE 0 /* mask pointer ignored (treated as all ones) */
@@ -54,7 +59,11 @@ enum {
 /* flags */
 #define CURL_F_EXACT_ORDER 0x1u /* evaluate each curve as the in-order fp32 sum of curves.py:31-32
                                    (no FMA contraction, torch's cascade order) instead of the collapsed
-                                   affine form a + b*x.  apply_curve / adjust_* only. */
+                                   affine form a + b*x.  apply_curve / adjust_*: bit-identical to the reference.
+                                   curl_lab_stage_f32 / curl_layer_fwd(_slab)_f32: the VALIDATION mode of the fused
+                                   stages -- the same in-order sums (knots and slopes of the image in LDS), every
+                                   `* mask` of model.py:154,160,166 executed, the converters' 1e-9 floors and refined
+                                   reciprocals kept: ~3x the default's time, for checking it, not for production. */
 #define CURL_F_PWL 0x2u         /* paper-style piecewise-linear curve (clamp (S*x-j) to [0,1]) -- NOT the
                                    reference's arithmetic; explicit non-parity option.  adjust_* and layer. */
 #define CURL_F_RESIDUAL_ONLY 0x4u /* curl_trispace_fwd_f32: write the residual instead of clamp(img + residual)

@@ -1146,3 +1146,84 @@ def test_hsv_stage_is_the_layers_third_stage(ops, dev, golden):
             ops.hsv_stage(x, m, Hk.to(dev), out=x)  # in place: every pixel is read before it is written
             assert torch.equal(x, got)
         np.testing.assert_allclose(N(reg), wreg.numpy(), rtol=2e-6)
+
+
+# ------------------------------------------------------------------ validation mode of the fused stages
+def test_fused_stages_exact_order_validation_mode(ops, dev, golden, big):
+    """CURL_F_EXACT_ORDER on curl_lab_stage_f32 / curl_layer_fwd_f32 (affine form as the default AND a
+    validation mode): every curve as the reference's term-by-term float32 sum (curves.py:31-32, ATen's cascade order),
+    every `* mask` executed, floors and refined reciprocals kept.  It must hold the golden bar like the default, agree
+    with the default to the size of the reference's own summation noise, and -- being the reference's arithmetic but for
+    the three hardware transcendentals -- may not be FURTHER from the reference than the default on a full-size frame."""
+    import curl_oracle as O
+    from curl_amd._lib import F_EXACT_ORDER
+    c = golden("chain")
+    L, R, H = (T(c["s01" + k], dev) for k in ("_L", "_R", "_H"))
+    for mk in ("ones", "holes", "soft"):
+        key = f"s01_img_{mk}"
+        for m in _mask_variants(c, mk, dev):
+            out, reg = ops.curl_layer_forward(T(c["img"], dev), m, L, R, H, flags=F_EXACT_ORDER)
+            assert max_err(N(out), c[key + "_out"]) <= 1e-5, key
+            np.testing.assert_allclose(N(reg), c[key + "_reg"], rtol=2e-6)
+            ls, _ = ops.lab_stage(T(c["img"], dev), m, L, flags=F_EXACT_ORDER)
+            assert max_err(N(ls), c[key + "_lab_stage"]) <= 1e-5, key
+            dflt, _ = ops.curl_layer_forward(T(c["img"], dev), m, L, R, H)
+            assert max_err(N(out), N(dflt)) <= 1e-5
+    with pytest.raises(ValueError):
+        ops.curl_layer_forward(T(c["img"], dev), None, L, R, H, flags=F_EXACT_ORDER | 2)  # exclusive with CURL_F_PWL
+    # full size: frame 1 of the conditioning test (well conditioned: strict 1e-5) and frame 0 (exception set)
+    img, mask, Lb, Rb, Hb = (t[:2] for t in big)
+    ex, _ = ops.curl_layer_forward(img, mask, Lb, Rb, Hb, flags=F_EXACT_ORDER)
+    df, _ = ops.curl_layer_forward(img, mask, Lb, Rb, Hb)
+    for b in (0, 1):
+        ref, _ = O.curl_layer(img[b:b + 1].cpu(), mask[b:b + 1].cpu().float(), Lb[b:b + 1].cpu(), Rb[b:b + 1].cpu(), Hb[b:b + 1].cpu())
+        d_ex = (ex[b:b + 1].cpu().double() - ref.double()).abs()
+        d_df = (df[b:b + 1].cpu().double() - ref.double()).abs()
+        n_ex, n_df = int((d_ex > 1e-5).sum()), int((d_df > 1e-5).sum())
+        print(f"frame {b}: px*ch over 1e-5 -- exact-order {n_ex} (max {float(d_ex.max()):.2e}), default {n_df} (max {float(d_df.max()):.2e})")
+        if b == 1:
+            assert n_ex == 0 and n_df == 0
+        else:
+            assert n_ex <= 1.5 * n_df + 50
+
+
+# ------------------------------------------------------------------ torch.chunk's uneven split (curves.py:53,105,152)
+def test_uneven_torch_chunk_split(ops, dev):
+    """A parameter count that does not divide by the number of curves: torch.chunk hands the first curves ceil(N/n) knots
+    and the last one the remainder (47 -> 16, 16, 15; 62 -> 16, 16, 16, 14).  The affine forms and the backward follow
+    it (CURL_K_UNEVEN); counts torch.chunk would split into FEWER chunks raise, as the reference's unpacking does."""
+    import curl_oracle as O
+    g = torch.Generator().manual_seed(47)
+    B, H, W = 2, 20, 36
+    img = torch.rand(B, 3, H, W, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.2
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (47, 46, 62))
+    for name, fn, k in (("rgb", "adjust_rgb", R), ("lab", "adjust_lab", L), ("hsv", "adjust_hsv", Hk)):
+        out, reg = getattr(ops, fn)(img.to(dev), k.to(dev))
+        want, wreg = getattr(O, fn)(img, k)
+        assert max_err(N(out), want.numpy()) <= 2e-6, name
+        np.testing.assert_allclose(N(reg), wreg.numpy(), rtol=2e-6)
+        with pytest.raises(ValueError):
+            getattr(ops, fn)(img.to(dev), k.to(dev), flags=1)  # exact-order mode: equal curves only
+    out, reg = ops.curl_layer_forward(img.to(dev), mask.to(dev), L.to(dev), R.to(dev), Hk.to(dev))
+    want, wreg = O.curl_layer(img, mask.float(), L, R, Hk, 47, 46, 62)
+    assert max_err(N(out), want.numpy()) <= 1e-5
+    np.testing.assert_allclose(N(reg), wreg.numpy(), rtol=2e-6)
+    ls, _ = ops.lab_stage(img.to(dev), mask.to(dev), L.to(dev))
+    assert max_err(N(ls), O.lab_stage(img, mask.float(), L, 47)[0].numpy()) <= 1e-5
+    hs, _ = ops.hsv_stage(img.to(dev), mask.to(dev), Hk.to(dev))
+    assert max_err(N(hs), O.hsv_stage(img, mask.float(), Hk, 62)[0].numpy()) <= 3e-6
+    # backward: knot gradients land on the right knots of the shorter last curve
+    w = torch.randn(B, 3, H, W, generator=g)
+    wr = torch.rand(B, generator=g)
+    x = img.clone().requires_grad_(True)
+    Lg, Rg, Hg = (t.clone().requires_grad_(True) for t in (L, R, Hk))
+    o, r = O.curl_layer(x, mask.float(), Lg, Rg, Hg, 47, 46, 62)
+    ((o * w).sum() + (r * wr).sum()).backward()
+    gi, gL, gR, gH = ops.curl_layer_backward(img.to(dev), mask.to(dev), L.to(dev), R.to(dev), Hk.to(dev), w.to(dev), wr.to(dev))
+    for a, b in ((gL, Lg.grad), (gR, Rg.grad), (gH, Hg.grad)):
+        assert float((a.cpu() - b).abs().max() / b.abs().max()) <= 1e-3
+    with pytest.raises(ValueError):
+        ops.adjust_rgb(img.to(dev), torch.zeros(B, 4, device=dev))   # torch.chunk(4, 3) gives two chunks of 2
+    with pytest.raises(ValueError):
+        ops.adjust_hsv(img.to(dev), torch.zeros(B, 13, device=dev))  # 4, 4, 4, 1: a one-knot curve

@@ -40,10 +40,18 @@ def test_knot_validation_helpers(monkeypatch):
     assert K == 16 and k.is_contiguous()
     k, K = ops._knots(torch.zeros(2, 100)[:, :64], "H", 4, 2)  # the slice H[:, :64] of a wider head
     assert K == 16 and k.is_contiguous()
-    with pytest.raises(ValueError, match="equal curves"):
-        ops._knots(torch.zeros(2, 50), "R", 3, 2)
-    with pytest.raises(ValueError, match="knots per curve"):
-        ops._knots(torch.zeros(2, 3), "R", 3, 2)
+    # torch.chunk's uneven split (curves.py:53,105,152): 50 -> 17, 17, 16, packed as K | K_last << 16 (CURL_K_UNEVEN)
+    _, K = ops._knots(torch.zeros(2, 50), "R", 3, 2)
+    assert K == 17 | (16 << 16)
+    _, K = ops._knots(torch.zeros(2, 62), "H", 4, 2)
+    assert K == 16 | (14 << 16)
+    for n, nc in ((3, 3), (13, 4), (4, 3), (9, 4)):  # one-knot curves; counts torch.chunk splits into fewer chunks than curves
+        with pytest.raises(ValueError, match="knots per curve|torch.chunk"):
+            ops._knots(torch.zeros(2, n), "R", nc, 2)
+    for n, nc in ((47, 3), (62, 4), (50, 3), (8, 3), (160, 4)):  # the split IS torch.chunk's
+        _, K = ops._knots(torch.zeros(2, n), "R", nc, 2)
+        sizes = [c.shape[1] for c in torch.chunk(torch.zeros(2, n), nc, dim=1)]
+        assert sizes == [K & 0xffff] * (nc - 1) + [(K >> 16) or (K & 0xffff)]
     with pytest.raises(ValueError):
         ops._knots(torch.zeros(3, 48), "R", 3, 2)
 

@@ -10,8 +10,8 @@ from pmc_summary import main as summarise  # noqa: E402
 
 tag = sys.argv[1]
 out = {}
-for workload, frag in (("layer", "OpLayer"), ("lab_stage", "OpLabStage"), ("rgb_only", "OpAdjust3"),
-                       ("trispace", "OpTriSpace")):
+for workload, frag in (("layer", "OpLayer"), ("lab_stage", "OpLabStage"), ("hsv_stage", "OpHsvStage"), ("rgb_only", "OpAdjust3"),
+                       ("trispace", "OpTriSpace"), ("layer_bwd", "layer_bwd_kernel")):
     root = os.path.join("gpurun_out", f"prof_{tag}_{workload}")
     if not os.path.isdir(root):
         continue

@@ -82,5 +82,18 @@ int main() {
 #define FLAT(T, UU) bench("flat T=" #T " U=" #UU, [&](v4f* src) { size_t nn = (size_t)B * 3 * n; hipLaunchKernelGGL((k_flat<UU>), dim3((unsigned)((nn + T * UU - 1) / (T * UU))), dim3(T), 0, 0, src, out, nn); });
   FLAT(256, 1) FLAT(256, 2) FLAT(256, 4) FLAT(512, 4) FLAT(1024, 4)
   bench("hipMemcpyAsync D2D", [&](v4f* src) { hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, 0); });
+  // sustained (round 3): 1000 launches after 200, as bench.py times its workloads -- the ceiling to hold the fused Lab
+  // stage's rocprofv3 figure against in ONE session on ONE box
+  auto sustained = [&](const char* name, auto launch) {
+    for (int i = 0; i < 200; ++i) launch(in[i & 1]);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 1000; ++i) launch(in[i & 1]);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 1000;
+    printf("sustained %-24s %7.1f us  %7.1f GB/s\n", name, ms * 1e3, 2.0 * bytes / ms / 1e6);
+  };
+#define STILE(T, UU, NTT) sustained("tile T=" #T " U=" #UU " nt=" #NTT, [&](v4f* src) { hipLaunchKernelGGL((k_tile<UU, NTT>), dim3((n + T * UU - 1) / (T * UU), B), dim3(T), 0, 0, src, out, n); });
+  STILE(256, 1, 1) STILE(256, 2, 1) STILE(256, 2, 0)
   return 0;
 }
