@@ -379,6 +379,35 @@ CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, cons
   for (int i = 0; i < M; ++i) out[i] = blend(neg_mask(d[i]), b[i], a[i]);
 }
 
+// The same select with a RARE first branch: out = (x <= thr) ? a(i) : b, where a() is only evaluated -- and the select only
+// executed -- if some lane of the wavefront has some x <= thr.  The compares are needed either way; their 64-lane results
+// sit in SGPR pairs, OR-ed by the scalar unit, and one wave-uniform branch skips M x (branch value + v_cndmask) VALU
+// instructions.  The four threshold selects of the Lab converters pick their linear branch for dark values only (sRGB
+// x <= 0.04045, XYZ t <= 0.008856, f <= 6/29, linear v <= 0.0031308): a wave of a photograph's mid-tones takes none of them;
+// of uniformly random pixels (the benchmark) ~30 % of the waves skip the two XYZ-side ones.  The kernel runs at the board's
+// power cap, where instructions are joules.  CURL_NO_LAZY_SELECT rebuilds the eager form.
+#if defined(CURL_SELECT_CNDMASK) && !defined(CURL_NO_LAZY_SELECT)
+#define CURL_LAZY_SELECT 1
+template <int M, class A>
+__device__ __forceinline__ void select_le_lazy(float (&out)[M], const float (&x)[M], float thr, A a, const float (&b)[M]) {
+  unsigned long long m[M], any = 0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m[i]) : "v"(x[i]), "s"(thr));
+    any |= m[i];
+  }
+  if (any) {
+    float av[M];
+    a(av);
+#pragma unroll
+    for (int i = 0; i < M; ++i) asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out[i]) : "v"(b[i]), "v"(av[i]), "s"(m[i]));
+  } else {
+#pragma unroll
+    for (int i = 0; i < M; ++i) out[i] = b[i];
+  }
+}
+#endif
+
 // y[i] = x[i]^e for M values: M logs, M multiplies, M exps
 template <int M>
 CURL_HD void pow_run(float (&x)[M], float e) {
@@ -434,8 +463,15 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
   mul_run(u2, g, g);
   pow_run(g, kGammaFrac);
   mul_run(g, u2, g);
+#if defined(CURL_LAZY_SELECT)
+  {
+    const float (&xr)[3 * N] = x;
+    select_le_lazy(x, x, kSrgbThr, [&](float (&av)[3 * N]) { scale_run(av, xr, kInv1292); }, g);
+  }
+#else
   scale_run(lin, x, kInv1292);
   select_le_run(x, x, kSrgbThr, lin, g);
+#endif
   // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white, folded into the rows)
   float t[3 * N], f[3 * N];
   {
@@ -450,8 +486,15 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 #pragma unroll
   for (int i = 0; i < 3 * N; ++i) f[i] = t[i];
   pow_run(f, kThird);
+#if defined(CURL_LAZY_SELECT)
+  {
+    const float (&tr)[3 * N] = t;
+    select_le_lazy(f, t, kEps3, [&](float (&av)[3 * N]) { fma_run(av, tr, kInv3Eps2, k4_29); }, f);
+  }
+#else
   fma_run(lin, t, kInv3Eps2, k4_29);
   select_le_run(f, t, kEps3, lin, f);
+#endif
   // colors.py:18-20,50: L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz);
   // colors.py:57-59: L/100, (a/110 + 1)/2, (b/110 + 1)/2 -- constants folded.
 #pragma unroll
@@ -479,10 +522,15 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   {
     // colors.py:110-111 ; x**3.0 is x*x*x in torch (cube taken only for f > eps > 1e-4)
     float cub[3 * N];
-    fma_run(lin, X, k3Eps2, -(k3Eps2 * k4_29));
     mul_run(cub, X, X);
     mul_run(cub, cub, X);
+#if defined(CURL_LAZY_SELECT)
+    const float (&Xr)[3 * N] = X;
+    select_le_lazy(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
+#else
+    fma_run(lin, X, k3Eps2, -(k3Eps2 * k4_29));
     select_le_run(X, X, kEps, lin, cub);
+#endif
   }
   {
     // colors.py:114 (x white) folded into the columns of colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
@@ -499,8 +547,13 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   pow_run(g, kInvGamma);
   if (!CLAMP12) {
     fma_run(g, g, 1.055f, -0.055f);
+#if defined(CURL_LAZY_SELECT)
+    const float (&vr)[3 * N] = v;
+    select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
+#else
     scale_run(lin, v, 12.92f);
     select_le_run(v, v, kLinThr, lin, g);
+#endif
   } else {
     // The next consumer (adjust3, curves.py:36) clamps channels 1 and 2 before using them.  A clamp after the
     // bitwise select is a separate v_max; on the two branches it rides on the fma / mul that produce them
@@ -513,12 +566,27 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     rsub_run(d, kLinThr, v);
 #pragma unroll
     for (int i = 0; i < N; ++i) g[i] = g0[i], lin[i] = l0[i];
+#if defined(CURL_LAZY_SELECT)
+#pragma unroll
+    for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
+    {
+      const float (&vr)[3 * N] = v;
+      select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) av[i] = vr[i] * 12.92f;
+#pragma unroll
+        for (int i = N; i < 3 * N; ++i) av[i] = clamp01(vr[i] * vconst(12.92f));
+      }, g);
+    }
+#else
 #pragma unroll
     for (int i = N; i < 3 * N; ++i) {
       g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
       lin[i] = clamp01(v[i] * vconst(12.92f));
     }
-#if defined(CURL_SELECT_CNDMASK)
+#endif
+#if defined(CURL_LAZY_SELECT)
+#elif defined(CURL_SELECT_CNDMASK)
 #pragma unroll
     for (int i = 0; i < 3 * N; ++i) v[i] = select_le_hw(v[i], kLinThr, lin[i], g[i]);
 #else

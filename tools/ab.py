@@ -29,7 +29,8 @@ def main():
     B, H, W = int(os.environ.get("B", 32)), int(os.environ.get("H", 1000)), int(os.environ.get("W", 1500))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    imgs = [torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
+    lo = float(os.environ.get("IMG_LO", 0.0))  # IMG_LO=0.2: no dark pixels (a photograph's mid-tones): pixels = lo + (1 - lo) U
+    imgs = [lo + (1.0 - lo) * torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
     out = torch.empty_like(imgs[0])
     mask = torch.ones(B, 1, H, W, dtype=torch.uint8, device=dev)
     L, R, Hk = (torch.randn(B, n, device=dev) * 0.1 for n in (48, 48, 64))
@@ -67,7 +68,9 @@ def main():
         assert rc == 0, rc
 
     extra = {"A": int(os.environ.get("FLAGS_A", "0"), 0), "B": int(os.environ.get("FLAGS_B", "0"), 0)}  # e.g. 0x200 = U=2
-    variants = [(k, d) for d in ((0,) if what == "layer_bwd" else (0, _lib.F_DIAG_NO_MEM)) for k in ("A", "B")]
+    full_only = what == "layer_bwd" or os.environ.get("FULL_ONLY")  # FULL_ONLY=1: skip the arithmetic-only (no-memory) legs
+    variants = [(k, d) for d in ((0,) if full_only else (0, _lib.F_DIAG_NO_MEM)) for k in ("A", "B")]
+    LAUNCHES = int(os.environ.get("LAUNCHES", 100))  # per timed window
     times = {v: [] for v in variants}
     for _ in range(150):  # clock settle
         run(libs["A"], 0)
@@ -78,11 +81,11 @@ def main():
                 run(libs[v[0]], v[1] | extra[v[0]])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(100):
+            for _ in range(LAUNCHES):
                 run(libs[v[0]], v[1] | extra[v[0]])
             e1.record()
             torch.cuda.synchronize()
-            times[v].append(e0.elapsed_time(e1) / 100)
+            times[v].append(e0.elapsed_time(e1) / LAUNCHES)
     # paired view: A and B of one round run within ~50 ms of each other, so the board's slow power / thermal drift (which
     # moves a power-capped kernel by +-2 % over a session) cancels in the per-round difference
     for d in sorted({v[1] for v in variants}):

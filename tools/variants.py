@@ -54,6 +54,7 @@ VARIANTS = {
     "r2_hsv": ["-DCURL_R2_HSV"],  # round-2 HSV code: hsv2rgb as two saturated ramps + two fmas per channel (default: one trapezoid), s masked by df != 0
     "bwd_interleave": ["-DCURL_BWD_INTERLEAVE"],  # layer backward: the lane's four pixels left to the compiler to interleave
     "bwd_w4": ["-DCURL_BWD_WAVES=4"],  # layer backward held to 128 VGPRs (four waves per SIMD; 72 bytes of scratch per lane)
+    "nolazy": ["-DCURL_NO_LAZY_SELECT"],  # the Lab converters' threshold selects always executed (default: skipped by waves that need none)
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
