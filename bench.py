@@ -383,7 +383,19 @@ def train_step_record(device, rank, world, local, dist):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     args = SimpleNamespace(steps=20, warmup=8, size=256, batch=32, width=1.0)
-    return mod.run(args, device, rank, world, local, dist)
+    # DDP wants the index of the device this rank computes on (on a rehearsal box ranks wrap onto the GPUs there are)
+    return mod.run(args, device, rank, world, device.index or 0, dist)
+
+
+def train_step_preflight(device):
+    """One forward / backward of the train step's model on this rank alone (no collective): what can fail -- building the
+    encoder, MIOpen's first solver search, memory -- fails here, on its own."""
+    from curl_amd import model
+    net = model.GCURLNet(backbone=model.CurveEncoder(160, width=1.0)).to(device).train()
+    img = torch.rand(4, 3, 256, 256, device=device)
+    out, reg = net(img, torch.ones(4, 1, 256, 256, dtype=torch.bool, device=device))
+    (out.mean() + 1e-6 * reg.mean()).backward()
+    torch.cuda.synchronize(device)
 
 
 def _cpu_model():
@@ -572,9 +584,24 @@ def main():
                 others.append(measure(name, max(200, args.steps // 2), max(3, args.warmup // 2)))
 
     train = None
-    if not args.no_extras:
-        try:  # every rank takes part (DDP's all-reduce); context only, never at the expense of the line
-            train = train_step_record(device, rank, world, local, dist)
+    if not args.no_extras and os.environ.get("CURL_BENCH_TRAIN_STEP", "1") != "0":
+        # Every rank takes part (DDP's all-reduce), so a failure on ONE rank must not leave the others waiting in a
+        # collective: the ranks first agree (one MIN all-reduce) that each of them could build the model and run a step
+        # alone; only then does the data-parallel measurement start.  Context only, never at the expense of the line.
+        try:
+            ok = 1.0
+            try:
+                train_step_preflight(device)
+            except Exception as e:
+                ok, train = 0.0, {"error": "preflight: " + repr(e)}
+            if dist is not None:
+                t = torch.tensor([ok], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = float(t[0])
+            if ok == 1.0:
+                train = train_step_record(device, rank, world, local, dist)
+            elif train is None:
+                train = {"error": "skipped: another rank failed the preflight"}
         except Exception as e:
             train = {"error": repr(e)}
 
