@@ -20,6 +20,11 @@
 // hipcc emits for `?:` that costs 23).  Constant factors of the derivatives (3 of the cube, 1/3 of the cube
 // root, 2.4/1.055 ...) ride on the constants of the linear maps behind them.
 //
+// (Tried and withdrawn: skipping the converters' rare linear branches per wave as the forward kernel does
+// (select_le_lazy).  With one pixel per lane at a time a branch covers three values, not twelve, and its compare ->
+// SGPR -> scalar OR -> branch latency sits in the only chain the wave has: +2.5 % at full frames, +4.6 % on the training
+// crop batch, -0.9 % even where every wave skips -- profiles/r03/exp8_bwd_lazy_branches_lost.log.)
+//
 // Same dual compilation as curl_math.h (device: gfx950 kernels; host: the test-only twin, predicates as bool).
 #pragma once
 #include "curl_math.h"
