@@ -445,7 +445,9 @@ CURL_HD void mat_row(float (&y)[N], const float (&a)[3 * N], float m0, float m1,
 }
 
 // ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
-template <int N>
+// LAZY: the two threshold selects through select_le_lazy (the fused curve stages ask for it; the polynomial model's
+// kernel, already at its register budget, spills 1.1 KB per lane with the twelve predicates live across a branch: 0.9 -> 6 ms)
+template <int N, bool LAZY = false>
 CURL_HD void rgb2lab_n(PxN<N>& p) {
   float x[3 * N], g[3 * N], u2[3 * N], lin[3 * N];
 #pragma unroll
@@ -464,14 +466,15 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
   pow_run(g, kGammaFrac);
   mul_run(g, u2, g);
 #if defined(CURL_LAZY_SELECT)
-  {
+  if constexpr (LAZY) {
     const float (&xr)[3 * N] = x;
     select_le_lazy(x, x, kSrgbThr, [&](float (&av)[3 * N]) { scale_run(av, xr, kInv1292); }, g);
-  }
-#else
-  scale_run(lin, x, kInv1292);
-  select_le_run(x, x, kSrgbThr, lin, g);
+  } else
 #endif
+  {
+    scale_run(lin, x, kInv1292);
+    select_le_run(x, x, kSrgbThr, lin, g);
+  }
   // colors.py:10-12,40 (OpenCV matrix) then colors.py:41 (x 1/white, folded into the rows)
   float t[3 * N], f[3 * N];
   {
@@ -487,14 +490,15 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
   for (int i = 0; i < 3 * N; ++i) f[i] = t[i];
   pow_run(f, kThird);
 #if defined(CURL_LAZY_SELECT)
-  {
+  if constexpr (LAZY) {
     const float (&tr)[3 * N] = t;
     select_le_lazy(f, t, kEps3, [&](float (&av)[3 * N]) { fma_run(av, tr, kInv3Eps2, k4_29); }, f);
-  }
-#else
-  fma_run(lin, t, kInv3Eps2, k4_29);
-  select_le_run(f, t, kEps3, lin, f);
+  } else
 #endif
+  {
+    fma_run(lin, t, kInv3Eps2, k4_29);
+    select_le_run(f, t, kEps3, lin, f);
+  }
   // colors.py:18-20,50: L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz);
   // colors.py:57-59: L/100, (a/110 + 1)/2, (b/110 + 1)/2 -- constants folded.
 #pragma unroll
@@ -507,7 +511,7 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 }
 
 // ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
-template <int N, bool CLAMP12 = false>  // CLAMP12: also clamp channels 1 and 2 to [0,1] (fused stages, see below)
+template <int N, bool CLAMP12 = false, bool LAZY = false>  // CLAMP12: also clamp channels 1 and 2 to [0,1] (fused stages, see below)
 CURL_HD void lab2rgb_n(PxN<N>& p) {
   float X[3 * N], v[3 * N], g[3 * N], lin[3 * N];
 #pragma unroll
@@ -525,12 +529,15 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     mul_run(cub, X, X);
     mul_run(cub, cub, X);
 #if defined(CURL_LAZY_SELECT)
-    const float (&Xr)[3 * N] = X;
-    select_le_lazy(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
-#else
-    fma_run(lin, X, k3Eps2, -(k3Eps2 * k4_29));
-    select_le_run(X, X, kEps, lin, cub);
+    if constexpr (LAZY) {
+      const float (&Xr)[3 * N] = X;
+      select_le_lazy(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
+    } else
 #endif
+    {
+      fma_run(lin, X, k3Eps2, -(k3Eps2 * k4_29));
+      select_le_run(X, X, kEps, lin, cub);
+    }
   }
   {
     // colors.py:114 (x white) folded into the columns of colors.py:71-73,117 (Lindbloom sRGB D65 inverse)
@@ -548,12 +555,15 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   if (!CLAMP12) {
     fma_run(g, g, 1.055f, -0.055f);
 #if defined(CURL_LAZY_SELECT)
-    const float (&vr)[3 * N] = v;
-    select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
-#else
-    scale_run(lin, v, 12.92f);
-    select_le_run(v, v, kLinThr, lin, g);
+    if constexpr (LAZY) {
+      const float (&vr)[3 * N] = v;
+      select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
+    } else
 #endif
+    {
+      scale_run(lin, v, 12.92f);
+      select_le_run(v, v, kLinThr, lin, g);
+    }
   } else {
     // The next consumer (adjust3, curves.py:36) clamps channels 1 and 2 before using them.  A clamp after the
     // bitwise select is a separate v_max; on the two branches it rides on the fma / mul that produce them
@@ -567,9 +577,9 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #pragma unroll
     for (int i = 0; i < N; ++i) g[i] = g0[i], lin[i] = l0[i];
 #if defined(CURL_LAZY_SELECT)
+    if constexpr (LAZY) {
 #pragma unroll
-    for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
-    {
+      for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
       const float (&vr)[3 * N] = v;
       select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) {
 #pragma unroll
@@ -577,22 +587,22 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #pragma unroll
         for (int i = N; i < 3 * N; ++i) av[i] = clamp01(vr[i] * vconst(12.92f));
       }, g);
-    }
+    } else
+#endif
+    {
+#pragma unroll
+      for (int i = N; i < 3 * N; ++i) {
+        g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
+        lin[i] = clamp01(v[i] * vconst(12.92f));
+      }
+#if defined(CURL_SELECT_CNDMASK)
+#pragma unroll
+      for (int i = 0; i < 3 * N; ++i) v[i] = select_le_hw(v[i], kLinThr, lin[i], g[i]);
 #else
 #pragma unroll
-    for (int i = N; i < 3 * N; ++i) {
-      g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
-      lin[i] = clamp01(v[i] * vconst(12.92f));
+      for (int i = 0; i < 3 * N; ++i) v[i] = blend(neg_mask(d[i]), g[i], lin[i]);
+#endif
     }
-#endif
-#if defined(CURL_LAZY_SELECT)
-#elif defined(CURL_SELECT_CNDMASK)
-#pragma unroll
-    for (int i = 0; i < 3 * N; ++i) v[i] = select_le_hw(v[i], kLinThr, lin[i], g[i]);
-#else
-#pragma unroll
-    for (int i = 0; i < 3 * N; ++i) v[i] = blend(neg_mask(d[i]), g[i], lin[i]);
-#endif
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -895,7 +905,7 @@ struct LayerCoef {
 // multiply is dropped for m == 1, and pixels with m == 0 are finished by the caller (lab_stage_masked_out).
 template <bool BINARY, int N, bool CLAMP12 = false>
 CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
-  rgb2lab_n<N>(p);
+  rgb2lab_n<N, true>(p);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k[0], k[1], k[2]);
@@ -906,7 +916,7 @@ CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
     }
     p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
   }
-  lab2rgb_n<N, CLAMP12>(p);
+  lab2rgb_n<N, CLAMP12, true>(p);
 }
 // what model.py:154-157 yields where the mask is 0: lab2rgb(0,0,0), the same colour for every such pixel
 CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }

@@ -312,7 +312,7 @@ def test_errors_on_device(ops, dev):
     with pytest.raises(ValueError):
         ops.apply_curve(x, torch.ones(1, 16, device=dev), None, 3, 0)
     with pytest.raises(ValueError):
-        ops.adjust_rgb(x, torch.zeros(1, 50, device=dev))
+        ops.adjust_rgb(x, torch.zeros(1, 4, device=dev))  # torch.chunk(4, 3): two chunks -- the reference's unpacking fails
     with pytest.raises(ValueError):
         ops.curl_layer_forward(x, torch.ones(1, 1, 5, 4, device=dev), *(torch.zeros(1, n, device=dev) for n in (48, 48, 64)))
     with pytest.raises(ValueError):
