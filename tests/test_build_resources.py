@@ -40,7 +40,7 @@ def test_no_product_kernel_spills(kernels):
 @pytest.mark.parametrize("frag,max_vgprs", [
     ("stream_kernelI7OpLayerLi4ELi1ELi1ELb1ELi0E", 64),        # fused layer, bool mask: 8 waves per SIMD
     ("stream_kernelI10OpLabStageLi4ELi1ELi1ELb1ELi0E", 64),
-    ("stream_kernelI10OpHsvStageLi4ELi1ELi1ELb1ELi0E", 64),
+    ("stream_kernelI10OpHsvStageLi4ELi2ELi1ELb1ELi0E", 64),
     ("stream_kernelI14OpTriSpaceRowsLi4ELi1ELi0ELb1ELi0E", 128),  # polynomial model: 4 waves per SIMD
     ("layer_bwd_kernelILi4ELi1E", 168),                          # layer backward: 3 waves per SIMD
 ])
