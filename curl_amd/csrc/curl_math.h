@@ -396,15 +396,19 @@ __device__ __forceinline__ void select_le_lazy(float (&out)[M], const float (&x)
     asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m[i]) : "v"(x[i]), "s"(thr));
     any |= m[i];
   }
+  // the select works IN PLACE on b's registers, so the skipping path is empty (as "out = m ? a : b" on one side and
+  // "out = b" on the other the register allocator left twelve copies on the skipping side)
+  float r[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) r[i] = b[i];
   if (any) {
     float av[M];
     a(av);
 #pragma unroll
-    for (int i = 0; i < M; ++i) asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out[i]) : "v"(b[i]), "v"(av[i]), "s"(m[i]));
-  } else {
-#pragma unroll
-    for (int i = 0; i < M; ++i) out[i] = b[i];
+    for (int i = 0; i < M; ++i) asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(av[i]), "s"(m[i]));
   }
+#pragma unroll
+  for (int i = 0; i < M; ++i) out[i] = r[i];
 }
 #endif
 
