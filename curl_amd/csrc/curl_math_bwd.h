@@ -54,11 +54,6 @@ __device__ __forceinline__ lmask lm_neg(float a) {  // a < 0
   asm("v_cmp_gt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
   return m;
 }
-__device__ __forceinline__ lmask lm_nonzero(float a) {  // a != 0 (false for NaN too: never fed one)
-  lmask m;
-  asm("v_cmp_lg_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
-  return m;
-}
 __device__ __forceinline__ float lm_sel(lmask m, float a, float b) {  // m ? a : b  (the value not taken may be NaN)
   float r;
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
@@ -82,7 +77,6 @@ inline lmask lm_eq_u(float a, float b) { return a == b; }
 inline lmask lm_le_u(float a, float b) { return a <= b; }
 inline lmask lm_lt_u(float a, float b) { return a < b; }
 inline lmask lm_neg(float a) { return a < 0.0f; }
-inline lmask lm_nonzero(float a) { return a != 0.0f; }
 inline float lm_sel(lmask m, float a, float b) { return m ? a : b; }
 inline float lm_keep(lmask m, float a) { return m ? a : 0.0f; }
 inline lmask lm_and(lmask a, lmask b) { return a && b; }
