@@ -73,6 +73,10 @@ enum {
 #define CURL_F_TUNE_UNROLL_MASK 0x700u
 #define CURL_F_TUNE_BLOCK_SHIFT 11 /* bits 11..12: threads per workgroup of the streaming kernels, 0 = 256, 1 = 128, 2 = 64 */
 #define CURL_F_TUNE_BLOCK_MASK 0x1800u
+#define CURL_F_TUNE_XCD_SHIFT 13   /* bits 13..14: workgroup -> tile mapping of the streaming kernels: 0 = library default,
+                                      1 = plain (workgroup b takes tile b), 2 = XCD-contiguous (the 8 XCDs, which are dealt
+                                      workgroups round-robin, each own one contiguous eighth of an image's tiles) */
+#define CURL_F_TUNE_XCD_MASK 0x6000u
 #define CURL_F_TUNE_NO_NT 0x8000u     /* plain loads/stores instead of the default non-temporal ones */
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */

@@ -1227,3 +1227,22 @@ def test_uneven_torch_chunk_split(ops, dev):
         ops.adjust_rgb(img.to(dev), torch.zeros(B, 4, device=dev))   # torch.chunk(4, 3) gives two chunks of 2
     with pytest.raises(ValueError):
         ops.adjust_hsv(img.to(dev), torch.zeros(B, 13, device=dev))  # 4, 4, 4, 1: a one-knot curve
+
+
+def test_xcd_contiguous_tile_mapping_is_the_same_result(ops, dev):
+    """CURL_F_TUNE_XCD = 2 (each XCD walks one contiguous eighth of an image's tiles; a lost experiment kept as a tuning
+    bit) only renumbers which workgroup takes which tile: identical bits, ragged tile counts and the
+    padding workgroups of the last eighth included."""
+    XCD = 2 << 13
+    g = torch.Generator().manual_seed(8)
+    for B, H, W in ((2, 300, 500), (1, 257, 1021), (3, 512, 512)):   # 147 / 257 (scalar path) / 256 tiles per image
+        img = torch.rand(B, 3, H, W, generator=g).to(dev)
+        mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+        L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+        a, ra = ops.curl_layer_forward(img, mask, L, R, Hk)
+        b, rb = ops.curl_layer_forward(img, mask, L, R, Hk, flags=XCD)
+        assert torch.equal(a, b) and torch.equal(ra, rb), (B, H, W)
+        assert torch.equal(ops.lab_stage(img, mask, L)[0], ops.lab_stage(img, mask, L, flags=XCD)[0])
+        assert torch.equal(ops.rgb2lab(img), ops.rgb2lab(img, flags=XCD))
+    with pytest.raises(ValueError):
+        ops.rgb2lab(img, flags=3 << 13)

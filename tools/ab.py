@@ -57,6 +57,11 @@ def main():
             rc = lib.curl_layer_bwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
                                         gout.data_ptr(), 0, gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
                                         ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, 0, stream)
+        elif what == "rgb2lab":
+            rc = lib.curl_rgb2lab_f32(img.data_ptr(), out.data_ptr(), B, H, W, flags, stream)
+        elif what == "adjust_rgb":
+            rc = lib.curl_adjust_rgb_f32(img.data_ptr(), R.data_ptr(), out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nb, B, H, W, 16,
+                                         flags, stream)
         elif what == "hsv_stage":
             rc = lib.curl_hsv_stage_f32(img.data_ptr(), mask.data_ptr(), 1, Hk.data_ptr(), out.data_ptr(), reg.data_ptr(),
                                         ws.data_ptr(), nb, B, H, W, 16, flags, stream)

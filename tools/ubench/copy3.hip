@@ -30,6 +30,40 @@ __global__ void k_tile(const v4f* __restrict__ in, v4f* __restrict__ out, unsign
     }
   }
 }
+// XCD-aware tile mapping (round 3): workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), so
+// with the plain mapping every XCD touches every eighth 4 KB tile of a plane.  MODE 1: XCD k owns the k-th contiguous
+// eighth of the image's tiles (tile = (b % 8) * ceil(T/8) + b / 8); MODE 2: eighths of 8-tile groups (64 KB runs).
+template <int U, int MODE>
+__global__ void k_tile_xcd(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned n, unsigned tiles) {
+  const unsigned img = blockIdx.y;
+  const size_t plane = n;
+  const v4f* p = in + (size_t)img * 3 * plane;
+  v4f* q = out + (size_t)img * 3 * plane;
+  unsigned b = blockIdx.x, tile;
+  if (MODE == 1) {
+    const unsigned per = (tiles + 7u) / 8u;
+    tile = (b & 7u) * per + (b >> 3);
+    if ((b >> 3) >= per || tile >= tiles) return;
+  } else {
+    const unsigned g = b >> 6, r = b & 63u;           // groups of 64 workgroups: XCD (r & 7) takes 8 consecutive tiles
+    tile = g * 64u + (r & 7u) * 8u + (r >> 3);
+    if (tile >= tiles) return;
+  }
+  unsigned base = tile * (blockDim.x * U) + threadIdx.x;
+  v4f a[U], bb[U], c[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = min(base + u * blockDim.x, n - 1);
+    a[u] = __builtin_nontemporal_load(p + i); bb[u] = __builtin_nontemporal_load(p + plane + i); c[u] = __builtin_nontemporal_load(p + 2 * plane + i);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * blockDim.x;
+    if (i < n) {
+      __builtin_nontemporal_store(a[u] * 1.01f, q + i); __builtin_nontemporal_store(bb[u] * 1.01f, q + plane + i); __builtin_nontemporal_store(c[u] * 1.01f, q + 2 * plane + i);
+    }
+  }
+}
 // persistent: grid = k * 256 CUs; each block strides over all (image, tile) pairs
 template <int U>
 __global__ void k_persist(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned n, unsigned tiles_per_img, unsigned total_tiles) {
@@ -95,5 +129,8 @@ int main() {
   };
 #define STILE(T, UU, NTT) sustained("tile T=" #T " U=" #UU " nt=" #NTT, [&](v4f* src) { hipLaunchKernelGGL((k_tile<UU, NTT>), dim3((n + T * UU - 1) / (T * UU), B), dim3(T), 0, 0, src, out, n); });
   STILE(256, 1, 1) STILE(256, 2, 1) STILE(256, 2, 0)
+#define SXCD(T, UU, MODE) sustained("xcd-aware mode " #MODE " T=" #T " U=" #UU, [&](v4f* src) { unsigned tiles = (n + T * UU - 1) / (T * UU); unsigned gx = MODE == 1 ? ((tiles + 7) / 8) * 8 : ((tiles + 63) / 64) * 64; hipLaunchKernelGGL((k_tile_xcd<UU, MODE>), dim3(gx, B), dim3(T), 0, 0, src, out, n, tiles); });
+  SXCD(256, 2, 1) SXCD(256, 2, 2) SXCD(256, 1, 1) SXCD(256, 1, 2)
+  STILE(256, 2, 1)
   return 0;
 }
