@@ -60,7 +60,13 @@ def main():
         "layer": lambda i: ops.curl_layer_forward(imgs[i & 1], ones, L, R, Hk, out=out),
         "layer_nomem": lambda i: ops.curl_layer_forward(imgs[i & 1], ones, L, R, Hk, out=out, flags=_lib.F_DIAG_NO_MEM),
         "trispace": lambda i: ops.trispace_forward(imgs[i & 1], poly),
+        # round 3
+        "hsv_stage": lambda i: ops.hsv_stage(imgs[i & 1], ones, Hk, out=out),
+        "layer_bright_pixels": lambda i: ops.curl_layer_forward(bright[i & 1], ones, L, R, Hk, out=out),
+        "layer_bwd": lambda i: ops.curl_layer_backward(imgs[i & 1], ones, L, R, Hk, imgs[1 - (i & 1)]),
+        "layer_exact_order": lambda i: ops.curl_layer_forward(imgs[i & 1], ones, L, R, Hk, out=out, flags=_lib.F_EXACT_ORDER),
     }
+    bright = [0.2 + 0.8 * t for t in imgs]  # no dark values: every wave skips the four linear branches
     res = {}
     for name, fn in work.items():
         samples, stop = [], [False]
