@@ -14,6 +14,7 @@
 // torch casts a Python scalar to the tensor dtype before the op.
 #pragma once
 #include <math.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define CURL_HD __host__ __device__ __forceinline__
@@ -388,6 +389,30 @@ CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, cons
 // power cap, where instructions are joules.  CURL_NO_LAZY_SELECT rebuilds the eager form.
 #if defined(CURL_SELECT_CNDMASK) && !defined(CURL_NO_LAZY_SELECT)
 #define CURL_LAZY_SELECT 1
+// ... and inside the branch the linear value is not computed for every lane and then selected: the multiply (or fma) itself
+// runs PREDICATED -- exec narrowed to the lanes whose compare said "linear branch" -- and overwrites the pow branch's value
+// in place there: one VALU instruction and two scalar ones per value instead of two VALU instructions (the scalar unit is
+// a pipe of its own).  s_and_saveexec / restore, so a caller's partial exec mask is respected.  CURL_NO_PRED_SELECT:
+// the v_cndmask form (A/B).
+#if !defined(CURL_NO_PRED_SELECT)
+#define CURL_PRED_SELECT 1
+__device__ __forceinline__ void pred_mul(float& dst, unsigned long long m, float x, float k_uniform) {  // dst = x * k where m
+  unsigned long long t;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_mul_f32_e32 %0, %4, %3\n\ts_mov_b64 exec, %1"
+      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform));
+}
+__device__ __forceinline__ void pred_mul_clamp(float& dst, unsigned long long m, float x, float k_uniform) {  // clamp01(x * k) where m
+  unsigned long long t;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_mul_f32_e64 %0, %4, %3 clamp\n\ts_mov_b64 exec, %1"
+      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform));
+}
+__device__ __forceinline__ void pred_fma(float& dst, unsigned long long m, float x, float k_uniform, float c_vgpr) {  // x * k + c where m
+  unsigned long long t;
+  asm("s_and_saveexec_b64 %1, %2\n\tv_fma_f32 %0, %3, %4, %5\n\ts_mov_b64 exec, %1"
+      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform), "v"(c_vgpr));
+}
+#endif
+// A(r, m): overwrite r[i] with the linear branch where m[i] (predicated form), or A(av): compute it for every lane
 template <int M, class A>
 __device__ __forceinline__ void select_le_lazy(float (&out)[M], const float (&x)[M], float thr, A a, const float (&b)[M]) {
   unsigned long long m[M], any = 0;
@@ -402,10 +427,14 @@ __device__ __forceinline__ void select_le_lazy(float (&out)[M], const float (&x)
 #pragma unroll
   for (int i = 0; i < M; ++i) r[i] = b[i];
   if (any) {
-    float av[M];
-    a(av);
+    if constexpr (std::is_invocable_v<A, float (&)[M], const unsigned long long (&)[M]>) {
+      a(r, m);  // predicated overwrites
+    } else {
+      float av[M];
+      a(av);
 #pragma unroll
-    for (int i = 0; i < M; ++i) asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(av[i]), "s"(m[i]));
+      for (int i = 0; i < M; ++i) asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(av[i]), "s"(m[i]));
+    }
   }
 #pragma unroll
   for (int i = 0; i < M; ++i) out[i] = r[i];
@@ -472,7 +501,14 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 #if defined(CURL_LAZY_SELECT)
   if constexpr (LAZY) {
     const float (&xr)[3 * N] = x;
+#if defined(CURL_PRED_SELECT)
+    select_le_lazy(x, x, kSrgbThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+#pragma unroll
+      for (int i = 0; i < 3 * N; ++i) pred_mul(r[i], m[i], xr[i], kInv1292);
+    }, g);
+#else
     select_le_lazy(x, x, kSrgbThr, [&](float (&av)[3 * N]) { scale_run(av, xr, kInv1292); }, g);
+#endif
   } else
 #endif
   {
@@ -496,7 +532,15 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 #if defined(CURL_LAZY_SELECT)
   if constexpr (LAZY) {
     const float (&tr)[3 * N] = t;
+#if defined(CURL_PRED_SELECT)
+    select_le_lazy(f, t, kEps3, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+      const float c = k4_29;
+#pragma unroll
+      for (int i = 0; i < 3 * N; ++i) pred_fma(r[i], m[i], tr[i], kInv3Eps2, c);
+    }, f);
+#else
     select_le_lazy(f, t, kEps3, [&](float (&av)[3 * N]) { fma_run(av, tr, kInv3Eps2, k4_29); }, f);
+#endif
   } else
 #endif
   {
@@ -535,7 +579,15 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #if defined(CURL_LAZY_SELECT)
     if constexpr (LAZY) {
       const float (&Xr)[3 * N] = X;
+#if defined(CURL_PRED_SELECT)
+      select_le_lazy(X, X, kEps, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+        const float c = -(k3Eps2 * k4_29);
+#pragma unroll
+        for (int i = 0; i < 3 * N; ++i) pred_fma(r[i], m[i], Xr[i], k3Eps2, c);
+      }, cub);
+#else
       select_le_lazy(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
+#endif
     } else
 #endif
     {
@@ -561,7 +613,14 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #if defined(CURL_LAZY_SELECT)
     if constexpr (LAZY) {
       const float (&vr)[3 * N] = v;
+#if defined(CURL_PRED_SELECT)
+      select_le_lazy(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+#pragma unroll
+        for (int i = 0; i < 3 * N; ++i) pred_mul(r[i], m[i], vr[i], 12.92f);
+      }, g);
+#else
       select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
+#endif
     } else
 #endif
     {
@@ -585,12 +644,21 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #pragma unroll
       for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
       const float (&vr)[3 * N] = v;
+#if defined(CURL_PRED_SELECT)
+      select_le_lazy(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) pred_mul(r[i], m[i], vr[i], 12.92f);
+#pragma unroll
+        for (int i = N; i < 3 * N; ++i) pred_mul_clamp(r[i], m[i], vr[i], 12.92f);
+      }, g);
+#else
       select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) {
 #pragma unroll
         for (int i = 0; i < N; ++i) av[i] = vr[i] * 12.92f;
 #pragma unroll
         for (int i = N; i < 3 * N; ++i) av[i] = clamp01(vr[i] * vconst(12.92f));
       }, g);
+#endif
     } else
 #endif
     {
