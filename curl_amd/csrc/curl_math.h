@@ -399,17 +399,17 @@ CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, cons
 __device__ __forceinline__ void pred_mul(float& dst, unsigned long long m, float x, float k_uniform) {  // dst = x * k where m
   unsigned long long t;
   asm("s_and_saveexec_b64 %1, %2\n\tv_mul_f32_e32 %0, %4, %3\n\ts_mov_b64 exec, %1"
-      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform));
+      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform) : "scc");  // s_and_saveexec writes SCC
 }
 __device__ __forceinline__ void pred_mul_clamp(float& dst, unsigned long long m, float x, float k_uniform) {  // clamp01(x * k) where m
   unsigned long long t;
   asm("s_and_saveexec_b64 %1, %2\n\tv_mul_f32_e64 %0, %4, %3 clamp\n\ts_mov_b64 exec, %1"
-      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform));
+      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform) : "scc");  // s_and_saveexec writes SCC
 }
 __device__ __forceinline__ void pred_fma(float& dst, unsigned long long m, float x, float k_uniform, float c_vgpr) {  // x * k + c where m
   unsigned long long t;
   asm("s_and_saveexec_b64 %1, %2\n\tv_fma_f32 %0, %3, %4, %5\n\ts_mov_b64 exec, %1"
-      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform), "v"(c_vgpr));
+      : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform), "v"(c_vgpr) : "scc");
 }
 #endif
 // A(r, m): overwrite r[i] with the linear branch where m[i] (predicated form), or A(av): compute it for every lane
