@@ -88,7 +88,7 @@ CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m
   }
   {
     PxN<2 * N> lab = x;
-    rgb2lab_n<2 * N>(lab);  // model.py:100-101 (+ clamp, model.py:55)
+    rgb2lab_n<2 * N>(lab);  // model.py:100-101 (+ clamp, model.py:55); eager selects: the lazy / predicated form moved nothing here (exp18)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int j = N + i;

@@ -47,6 +47,11 @@ def main():
     sb = libs["A"].curl_layer_bwd_scratch_bytes(B, H, W)
     scratch = torch.empty(max(4, sb) // 4, device=dev)
 
+    loss_sums = torch.empty(B, 5, dtype=torch.float64, device=dev)
+    loss_L = [torch.empty(B, 1, H, W, device=dev) for _ in range(2)] if what == "loss_fwd" else [out, out]
+    loss_nb = libs["A"].curl_loss_terms_scratch_bytes(B, H, W)
+    loss_scratch = torch.empty(max(4, loss_nb) // 4, device=dev)
+
     def run(lib, flags):
         cnt[0] += 1
         img = imgs[cnt[0] & 1]
@@ -57,6 +62,9 @@ def main():
             rc = lib.curl_layer_bwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
                                         gout.data_ptr(), 0, gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
                                         ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, 0, stream)
+        elif what == "loss_fwd":
+            rc = lib.curl_loss_terms_f32(img.data_ptr(), imgs[1 - (cnt[0] & 1)].data_ptr(), mask.data_ptr(), 1, loss_sums.data_ptr(),
+                                         loss_L[0].data_ptr(), loss_L[1].data_ptr(), loss_scratch.data_ptr(), loss_nb, B, H, W, stream)
         elif what == "rgb2lab":
             rc = lib.curl_rgb2lab_f32(img.data_ptr(), out.data_ptr(), B, H, W, flags, stream)
         elif what == "adjust_rgb":
@@ -73,7 +81,7 @@ def main():
         assert rc == 0, rc
 
     extra = {"A": int(os.environ.get("FLAGS_A", "0"), 0), "B": int(os.environ.get("FLAGS_B", "0"), 0)}  # e.g. 0x200 = U=2
-    full_only = what == "layer_bwd" or os.environ.get("FULL_ONLY")  # FULL_ONLY=1: skip the arithmetic-only (no-memory) legs
+    full_only = what in ("layer_bwd", "loss_fwd") or os.environ.get("FULL_ONLY")  # FULL_ONLY=1: skip the arithmetic-only (no-memory) legs
     variants = [(k, d) for d in ((0,) if full_only else (0, _lib.F_DIAG_NO_MEM)) for k in ("A", "B")]
     LAUNCHES = int(os.environ.get("LAUNCHES", 100))  # per timed window
     times = {v: [] for v in variants}
