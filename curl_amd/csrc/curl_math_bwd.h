@@ -23,7 +23,9 @@
 // (Tried and withdrawn: skipping the converters' rare linear branches per wave as the forward kernel does
 // (select_le_lazy).  With one pixel per lane at a time a branch covers three values, not twelve, and its compare ->
 // SGPR -> scalar OR -> branch latency sits in the only chain the wave has: +2.5 % at full frames, +4.6 % on the training
-// crop batch, -0.9 % even where every wave skips -- profiles/r03/exp8_bwd_lazy_branches_lost.log.)
+// crop batch, -0.9 % even where every wave skips -- profiles/r03/exp8_bwd_lazy_branches_lost.log.  Nor do the forward's
+// predicated overwrites pay here: -0.4 % at full frames, +2.7 % on the crop batch -- exp19_bwd_predicated_lost.log: every
+// exec switch sits in the one dependent chain a wave has.)
 //
 // Same dual compilation as curl_math.h (device: gfx950 kernels; host: the test-only twin, predicates as bool).
 #pragma once
