@@ -89,6 +89,10 @@ CURL_HD unsigned unit_to_u8(float x) {
   return (unsigned)(int)v;
 }
 
+// the same for a value KNOWN to lie in [0, 1] (the fused byte paths: both ops end in clamp(., 0, 1), and the white
+// compositing x m + (1 - m) of two values in [0, 1] stays there): the two saturation instructions go
+CURL_HD unsigned unit_to_u8_in_range(float x) { return (unsigned)(int)(x * 255.0f); }
+
 // ---------------------------------------------------------------- branch-free selects
 // Measured on MI355X (tools/ubench/valu_rate.hip): v_cndmask_b32 with its mask in VCC -- what hipcc emits
 // for `c ? a : b` -- issues once per ~23 cycles per SIMD, against 2 for v_fma/v_mul/v_add/shift/and/or and
