@@ -416,14 +416,16 @@ __device__ __forceinline__ void pred_fma(float& dst, unsigned long long m, float
       : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform), "v"(c_vgpr) : "scc");
 }
 #endif
-// A(r, m): overwrite r[i] with the linear branch where m[i] (predicated form), or A(av): compute it for every lane
-template <int M, class A>
+// A(r, m): overwrite r[i] with the linear branch where m[i] (predicated form), or A(av): compute it for every lane.
+// BRANCH = false: no wave-uniform skip, only the predicated overwrites (the predicates are consumed one by one instead of
+// being held across a branch: for kernels at their register budget)
+template <bool BRANCH = true, int M, class A>
 __device__ __forceinline__ void select_le_lazy(float (&out)[M], const float (&x)[M], float thr, A a, const float (&b)[M]) {
-  unsigned long long m[M], any = 0;
+  unsigned long long m[M], any = BRANCH ? 0ull : 1ull;
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m[i]) : "v"(x[i]), "s"(thr));
-    any |= m[i];
+    if (BRANCH) any |= m[i];
   }
   // the select works IN PLACE on b's registers, so the skipping path is empty (as "out = m ? a : b" on one side and
   // "out = b" on the other the register allocator left twelve copies on the skipping side)
@@ -484,7 +486,7 @@ CURL_HD void mat_row(float (&y)[N], const float (&a)[3 * N], float m0, float m1,
 // ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
 // LAZY: the two threshold selects through select_le_lazy (the fused curve stages ask for it; the polynomial model's
 // kernel, already at its register budget, spills 1.1 KB per lane with the twelve predicates live across a branch: 0.9 -> 6 ms)
-template <int N, bool LAZY = false>
+template <int N, int LAZY = 0>  // 0: eager selects, 1: skipped per wave + predicated, 2: predicated only
 CURL_HD void rgb2lab_n(PxN<N>& p) {
   float x[3 * N], g[3 * N], u2[3 * N], lin[3 * N];
 #pragma unroll
@@ -503,15 +505,15 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
   pow_run(g, kGammaFrac);
   mul_run(g, u2, g);
 #if defined(CURL_LAZY_SELECT)
-  if constexpr (LAZY) {
+  if constexpr (LAZY != 0) {
     const float (&xr)[3 * N] = x;
 #if defined(CURL_PRED_SELECT)
-    select_le_lazy(x, x, kSrgbThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+    select_le_lazy<LAZY == 1>(x, x, kSrgbThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
 #pragma unroll
       for (int i = 0; i < 3 * N; ++i) pred_mul(r[i], m[i], xr[i], kInv1292);
     }, g);
 #else
-    select_le_lazy(x, x, kSrgbThr, [&](float (&av)[3 * N]) { scale_run(av, xr, kInv1292); }, g);
+    select_le_lazy<LAZY == 1>(x, x, kSrgbThr, [&](float (&av)[3 * N]) { scale_run(av, xr, kInv1292); }, g);
 #endif
   } else
 #endif
@@ -534,16 +536,16 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
   for (int i = 0; i < 3 * N; ++i) f[i] = t[i];
   pow_run(f, kThird);
 #if defined(CURL_LAZY_SELECT)
-  if constexpr (LAZY) {
+  if constexpr (LAZY != 0) {
     const float (&tr)[3 * N] = t;
 #if defined(CURL_PRED_SELECT)
-    select_le_lazy(f, t, kEps3, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+    select_le_lazy<LAZY == 1>(f, t, kEps3, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
       const float c = k4_29;
 #pragma unroll
       for (int i = 0; i < 3 * N; ++i) pred_fma(r[i], m[i], tr[i], kInv3Eps2, c);
     }, f);
 #else
-    select_le_lazy(f, t, kEps3, [&](float (&av)[3 * N]) { fma_run(av, tr, kInv3Eps2, k4_29); }, f);
+    select_le_lazy<LAZY == 1>(f, t, kEps3, [&](float (&av)[3 * N]) { fma_run(av, tr, kInv3Eps2, k4_29); }, f);
 #endif
   } else
 #endif
@@ -563,7 +565,7 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 }
 
 // ---------------------------------------------------------------- Lab -> RGB   colors.py:88-123
-template <int N, bool CLAMP12 = false, bool LAZY = false>  // CLAMP12: also clamp channels 1 and 2 to [0,1] (fused stages, see below)
+template <int N, bool CLAMP12 = false, int LAZY = 0>  // CLAMP12: also clamp channels 1 and 2 to [0,1] (fused stages, see below); LAZY as in rgb2lab_n
 CURL_HD void lab2rgb_n(PxN<N>& p) {
   float X[3 * N], v[3 * N], g[3 * N], lin[3 * N];
 #pragma unroll
@@ -581,16 +583,16 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     mul_run(cub, X, X);
     mul_run(cub, cub, X);
 #if defined(CURL_LAZY_SELECT)
-    if constexpr (LAZY) {
+    if constexpr (LAZY != 0) {
       const float (&Xr)[3 * N] = X;
 #if defined(CURL_PRED_SELECT)
-      select_le_lazy(X, X, kEps, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+      select_le_lazy<LAZY == 1>(X, X, kEps, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
         const float c = -(k3Eps2 * k4_29);
 #pragma unroll
         for (int i = 0; i < 3 * N; ++i) pred_fma(r[i], m[i], Xr[i], k3Eps2, c);
       }, cub);
 #else
-      select_le_lazy(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
+      select_le_lazy<LAZY == 1>(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
 #endif
     } else
 #endif
@@ -615,15 +617,15 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   if (!CLAMP12) {
     fma_run(g, g, 1.055f, -0.055f);
 #if defined(CURL_LAZY_SELECT)
-    if constexpr (LAZY) {
+    if constexpr (LAZY != 0) {
       const float (&vr)[3 * N] = v;
 #if defined(CURL_PRED_SELECT)
-      select_le_lazy(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+      select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
 #pragma unroll
         for (int i = 0; i < 3 * N; ++i) pred_mul(r[i], m[i], vr[i], 12.92f);
       }, g);
 #else
-      select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
+      select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
 #endif
     } else
 #endif
@@ -644,19 +646,19 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
 #pragma unroll
     for (int i = 0; i < N; ++i) g[i] = g0[i], lin[i] = l0[i];
 #if defined(CURL_LAZY_SELECT)
-    if constexpr (LAZY) {
+    if constexpr (LAZY != 0) {
 #pragma unroll
       for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
       const float (&vr)[3 * N] = v;
 #if defined(CURL_PRED_SELECT)
-      select_le_lazy(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
+      select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
 #pragma unroll
         for (int i = 0; i < N; ++i) pred_mul(r[i], m[i], vr[i], 12.92f);
 #pragma unroll
         for (int i = N; i < 3 * N; ++i) pred_mul_clamp(r[i], m[i], vr[i], 12.92f);
       }, g);
 #else
-      select_le_lazy(v, v, kLinThr, [&](float (&av)[3 * N]) {
+      select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&av)[3 * N]) {
 #pragma unroll
         for (int i = 0; i < N; ++i) av[i] = vr[i] * 12.92f;
 #pragma unroll
@@ -981,7 +983,7 @@ struct LayerCoef {
 // multiply is dropped for m == 1, and pixels with m == 0 are finished by the caller (lab_stage_masked_out).
 template <bool BINARY, int N, bool CLAMP12 = false>
 CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
-  rgb2lab_n<N, true>(p);
+  rgb2lab_n<N, 1>(p);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     Px o = adjust3(Px{p.c0[i], p.c1[i], p.c2[i]}, k[0], k[1], k[2]);
@@ -992,7 +994,7 @@ CURL_HD void lab_stage_n(PxN<N>& p, const float (&m)[N], const Affine* k) {
     }
     p.c0[i] = o.c0, p.c1[i] = o.c1, p.c2[i] = o.c2;
   }
-  lab2rgb_n<N, CLAMP12, true>(p);
+  lab2rgb_n<N, CLAMP12, 1>(p);
 }
 // what model.py:154-157 yields where the mask is 0: lab2rgb(0,0,0), the same colour for every such pixel
 CURL_HD Px lab_stage_masked_out() { return lab2rgb(Px{0.0f, 0.0f, 0.0f}); }

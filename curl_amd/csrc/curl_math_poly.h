@@ -10,6 +10,9 @@
 // ~2.6 kFLOP per pixel: this kernel is VALU-bound by a wide margin (no MFMA shape fits: the contraction has
 // 3 output columns per 126-deep dot product, 3/16 of the smallest f32 MFMA tile, at the VALU's own rate).
 #pragma once
+#ifndef CURL_POLY_SEL
+#define CURL_POLY_SEL 0  // the converters' threshold selects inside the polynomial model: 0 eager; 2 (predicated) spills 688 B per lane at the kernel's 128-VGPR budget, 1 (skipped per wave too) 1.1 KB -- round 3
+#endif
 #include "curl_math_bwd.h"
 
 namespace curlm {
@@ -220,7 +223,7 @@ template <int V, int N, bool SEQ = false>
 CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], const float* coef, bool residual_only) {
   constexpr int NC = SEQ ? PolyEval<V>::kSeqStride : PolyEval<V>::kCoeffs;
   PxN<N> lab = p, hsv = p;
-  rgb2lab_n<N>(lab);
+  rgb2lab_n<N, CURL_POLY_SEL>(lab);
   rgb2hsv_n<N>(hsv);
   float vars[V][N], o[3][N];
   float res[3][N];
@@ -262,7 +265,7 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
     PxN<N> q;
 #pragma unroll
     for (int i = 0; i < N; ++i) q.c0[i] = o[0][i], q.c1[i] = o[1][i], q.c2[i] = o[2][i];
-    lab2rgb_n<N>(q);
+    lab2rgb_n<N, false, CURL_POLY_SEL>(q);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       res[0][i] += 2.0f * (q.c0[i] - 0.5f);
