@@ -79,8 +79,8 @@ WORKLOADS = {
                         bpp=6.0, frag="OpTriSpace", mask=None, bound="valu", flop_px=1473.0),
     # ---- BASELINE configs[4]'s kernels (the train step's custom HIP curve forward / backward and loss terms): VALU-bound,
     # rooflined against the 157.3 TFLOP/s vector peak; flop_px from the kernels' ISA (tools/flops_from_isa.py --all)
-    "layer_bwd": dict(desc="curve-layer BACKWARD (curl_layer_bwd_f32: d img + d raw knots; autograd of model.py:137-176) on 8 x "
-                           "1500x1000 frames, bool mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu",
+    "layer_bwd": dict(desc="curve-layer BACKWARD (curl_layer_bwd_f32: d img + d raw knots; autograd of model.py:137-176, the "
+                           "forward's knot workspace handed back as the autograd node does) on 8 x 1500x1000 frames, bool mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu",
                       flop_px=412.5, images=8),
     "layer_bwd_crop": dict(desc="curve-layer backward on the training crop batch, 32 x 256x256 (main.py:88, data.py:86), bool "
                                 "mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu", flop_px=412.5,
@@ -116,15 +116,21 @@ def make_step(name, ops, masks, sets=None):
             m = torch.ones(n, 1, h, wd, dtype=torch.bool, device=dev)
             turn = [0]
 
+            # as the autograd node runs it: the knot workspace the forward filled is handed back (CURL_F_WS_READY)
+            wss = [ops.curl_layer_forward(c[0], m, c[1], c[2], c[3], return_workspace=True)[2] for c in crops]
+
             def crop_step(_s):
-                c = crops[turn[0] % len(crops)]
+                k = turn[0] % len(crops)
+                c = crops[k]
                 turn[0] += 1
-                return ops.curl_layer_backward(c[0], m, c[1], c[2], c[3], gout)
+                return ops.curl_layer_backward(c[0], m, c[1], c[2], c[3], gout, workspace=wss[k])
             return crop_step
         gout = sets[1 % len(sets)][0][:n]  # any resident float image serves as the incoming gradient
         m = None if mask is None else mask[:n]
         if name == "layer_bwd":
-            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gout)
+            ws8 = [ops.curl_layer_forward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], return_workspace=True)[2] for s in sets]
+            ids = {id(s): k for k, s in enumerate(sets)}
+            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gout, workspace=ws8[ids[id(s)]])
         if name == "trispace_bwd":
             return lambda s: ops.trispace_backward(s[0][:n], s[4][:n], gout)
         other = sets[1 % len(sets)][0]

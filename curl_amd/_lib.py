@@ -20,6 +20,7 @@ F_TUNE_BLOCK_SHIFT = 11
 F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
 F_DIAG_SKIP_PREP = 0x20000
+F_WS_READY = 0x40000
 MAX_KNOTS = 256
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers

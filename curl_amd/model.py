@@ -16,17 +16,19 @@ class _CurlLayerFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # under autocast: float32 in, autocast off
     def forward(ctx, img, mask, L, R, H):
-        out, reg = ops.curl_layer_forward(img, mask, L, R, H)
-        ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous())
+        out, reg, ws = ops.curl_layer_forward(img, mask, L, R, H, return_workspace=True)
+        # the knot workspace (exp'd knots, collapsed curves: 768 B per image) rides along: the backward skips its prep launch
+        ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous(), ws)
         ctx.mask = mask
         return out, reg
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out, grad_reg):
-        img, L, R, H = ctx.saved_tensors
+        img, L, R, H, ws = ctx.saved_tensors
         need_img = ctx.needs_input_grad[0]
-        g_img, gL, gR, gH = ops.curl_layer_backward(img, ctx.mask, L, R, H, grad_out.contiguous(), grad_reg, need_img)
+        g_img, gL, gR, gH = ops.curl_layer_backward(img, ctx.mask, L, R, H, grad_out.contiguous(), grad_reg, need_img,
+                                                    workspace=ws)
         return g_img, None, gL, gR, gH
 
 

@@ -35,7 +35,7 @@ def _empty_ok(mask_arg=None):
                 kwargs.pop("out", None)
                 res = fn(img.new_zeros((B, 3, 1, 1)), *args, **kwargs)
                 reg = res[1]
-            return out, reg
+            return (out, reg, None) if kwargs.get("return_workspace") else (out, reg)
         return wrapper
     return deco
 
@@ -293,9 +293,11 @@ def hsv_stage(img, mask, H, flags=0, out=None):
 
 @_one_device
 @_empty_ok(mask_arg=0)
-def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
+def curl_layer_forward(img, mask, L, R, H, flags=0, out=None, return_workspace=False):
     """CURLLayer.forward (model.py:137-176) in one pass over the pixels. -> (img, reg[B]).
-    L [B,3*Kl], R [B,3*Kr], H [B,4*Kh] are the already-sliced raw knots."""
+    L [B,3*Kl], R [B,3*Kr], H [B,4*Kh] are the already-sliced raw knots.
+    return_workspace: also return the knot workspace the call filled (-> (img, reg, ws)); handed back to
+    curl_layer_backward(..., workspace=ws) it saves that call its knot-prep launch."""
     lib = _lib.load()
     img = _image(img)
     B, _, Hh, W = img.shape
@@ -310,7 +312,7 @@ def curl_layer_forward(img, mask, L, R, H, flags=0, out=None):
                                 out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nbytes, B, Hh, W, Kl, Kr, Kh,
                                 flags, _stream(img))
     _lib.check(rc, "curl_layer_fwd_f32")
-    return out, reg
+    return (out, reg, ws) if return_workspace else (out, reg)
 
 
 def _slab(rows, H):
@@ -363,9 +365,10 @@ def trispace_forward_rows(img, coeffs, rows, out, residual_only=False):
 
 
 @_one_device
-def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True):
+def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True, workspace=None):
     """Backward of curl_layer_forward (what autograd would run through model.py:137-176).
-    -> (grad_img or None, grad_L, grad_R, grad_H)."""
+    -> (grad_img or None, grad_L, grad_R, grad_H).
+    workspace: the tensor curl_layer_forward(..., return_workspace=True) returned for the SAME knots (CURL_F_WS_READY)."""
     lib = _lib.load()
     img = _image(img)
     grad_out = _image(grad_out, "grad_out")
@@ -384,12 +387,17 @@ def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_i
     g_img = torch.empty_like(img) if need_grad_img else None
     gL, gR, gH = torch.empty_like(Lc), torch.empty_like(Rc), torch.empty_like(Hc)
     ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], img.device)
+    bflags = 0
+    if workspace is not None:
+        if workspace.device != img.device or workspace.dtype != torch.float32 or workspace.numel() * 4 < nbytes:
+            raise ValueError("workspace is not the tensor curl_layer_forward returned for this batch")
+        ws, bflags = workspace, _lib.F_WS_READY
     sbytes = lib.curl_layer_bwd_scratch_bytes(B, Hh, W)
     scratch = torch.empty(sbytes // 4, dtype=torch.float32, device=img.device)
     rc = lib.curl_layer_bwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),
                                 grad_out.data_ptr(), _ptr(grad_reg), _ptr(g_img), gL.data_ptr(), gR.data_ptr(),
                                 gH.data_ptr(), ws.data_ptr(), nbytes, scratch.data_ptr(), sbytes, B, Hh, W, Kl, Kr, Kh,
-                                0, _stream(img))
+                                bflags, _stream(img))
     _lib.check(rc, "curl_layer_bwd_f32")
     return g_img, gL, gR, gH
 

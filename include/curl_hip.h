@@ -81,6 +81,9 @@ enum {
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */
 
+#define CURL_F_WS_READY 0x40000u /* curl_layer_bwd_f32: `workspace` is the buffer curl_layer_fwd_f32 (or an earlier backward) was
+                                    handed for the SAME raw knots and has not been written since: it already holds the
+                                    exp'd knots and collapsed curves, the knot-prep launch is skipped */
 #define CURL_F_DIAG_SKIP_PREP 0x20000u /* DIAGNOSTICS ONLY (curl_layer_fwd_f32): the knot-prep launch is skipped and the
                                          workspace is taken to hold an earlier call's result for the same knots; `reg`
                                          is not written.  Measures what the prep launch + its kernel boundary cost. */

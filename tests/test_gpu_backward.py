@@ -443,3 +443,29 @@ def test_trispace_backward_edge_geometries_vs_twin(ops, dev, twin, shape):
     want35 = twin.trispace_bwd(img.numpy(), coeffs[..., :35].contiguous().numpy(), w.numpy(), False)
     got35 = ops.trispace_backward(img.to(dev), coeffs[..., :35].contiguous().to(dev), w.to(dev))
     assert rel(got35, want35) <= 2e-5
+
+
+def test_backward_reuses_the_forward_workspace(ops, dev):
+    """CURL_F_WS_READY: the autograd node keeps the knot workspace the forward filled and the backward skips its prep
+    launch -- identical gradients, through ops and through CURLLayer; a workspace of the wrong size is refused."""
+    from curl_amd import model
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 3, 40, 52
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.2).to(dev)
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+    w = torch.randn(B, 3, H, W, generator=g).to(dev)
+    wr = torch.rand(B, generator=g).to(dev)
+    out, reg, ws = ops.curl_layer_forward(img, mask, L, R, Hk, return_workspace=True)
+    a = ops.curl_layer_backward(img, mask, L, R, Hk, w, wr)
+    b = ops.curl_layer_backward(img, mask, L, R, Hk, w, wr, workspace=ws)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        ops.curl_layer_backward(img, mask, L, R, Hk, w, wr, workspace=ws[:8])
+    layer = model.CURLLayer().to(dev)
+    x = img.clone().requires_grad_(True)
+    Lg, Rg, Hg = (t.clone().requires_grad_(True) for t in (L, R, Hk))
+    o, r = layer(x, mask, Lg, Rg, Hg)
+    ((o * w).sum() + (r * wr).sum()).backward()
+    assert torch.equal(x.grad, a[0]) and torch.equal(Lg.grad, a[1]) and torch.equal(Rg.grad, a[2]) and torch.equal(Hg.grad, a[3])
