@@ -64,6 +64,46 @@ __global__ void k_tile_xcd(const v4f* __restrict__ in, v4f* __restrict__ out, un
     }
   }
 }
+// Cache-policy bits of the streaming accesses (round 3): the nontemporal builtin emits `nt`; gfx940+ global accesses also
+// carry sc0 / sc1 (scope) bits.  LD / ST: 0 = nt (the product's), 1 = nt sc1, 2 = nt sc0 sc1, 3 = sc0 sc1, 4 = plain.
+template <int LD>
+__device__ __forceinline__ v4f ld_pol(const v4f* p) {
+  v4f v;
+  if (LD == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  else if (LD == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+  else if (LD == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+  else if (LD == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int ST>
+__device__ __forceinline__ void st_pol(v4f* p, v4f v) {
+  if (ST == 0) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  else if (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+  else if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+  else if (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+template <int U, int LD, int ST>
+__global__ void k_tile_pol(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned n) {
+  const unsigned img = blockIdx.y;
+  const size_t plane = n;
+  const v4f* p = in + (size_t)img * 3 * plane;
+  v4f* q = out + (size_t)img * 3 * plane;
+  unsigned base = blockIdx.x * (blockDim.x * U) + threadIdx.x;
+  v4f a[U], b[U], c[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = min(base + u * blockDim.x, n - 1);
+    a[u] = ld_pol<LD>(p + i); b[u] = ld_pol<LD>(p + plane + i); c[u] = ld_pol<LD>(p + 2 * plane + i);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned i = base + u * blockDim.x;
+    if (i < n) { st_pol<ST>(q + i, a[u] * 1.01f); st_pol<ST>(q + plane + i, b[u] * 1.01f); st_pol<ST>(q + 2 * plane + i, c[u] * 1.01f); }
+  }
+}
 // persistent: grid = k * 256 CUs; each block strides over all (image, tile) pairs
 template <int U>
 __global__ void k_persist(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned n, unsigned tiles_per_img, unsigned total_tiles) {
@@ -131,6 +171,12 @@ int main() {
   STILE(256, 1, 1) STILE(256, 2, 1) STILE(256, 2, 0)
 #define SXCD(T, UU, MODE) sustained("xcd-aware mode " #MODE " T=" #T " U=" #UU, [&](v4f* src) { unsigned tiles = (n + T * UU - 1) / (T * UU); unsigned gx = MODE == 1 ? ((tiles + 7) / 8) * 8 : ((tiles + 63) / 64) * 64; hipLaunchKernelGGL((k_tile_xcd<UU, MODE>), dim3(gx, B), dim3(T), 0, 0, src, out, n, tiles); });
   SXCD(256, 2, 1) SXCD(256, 2, 2) SXCD(256, 1, 1) SXCD(256, 1, 2)
+  STILE(256, 2, 1)
+#define SPOL(UU, LD, ST) sustained("policy U=" #UU " ld=" #LD " st=" #ST, [&](v4f* src) { hipLaunchKernelGGL((k_tile_pol<UU, LD, ST>), dim3((n + 256 * UU - 1) / (256 * UU), B), dim3(256), 0, 0, src, out, n); });
+  SPOL(2, 0, 0) SPOL(2, 1, 0) SPOL(2, 2, 0) SPOL(2, 3, 0) SPOL(2, 4, 0)
+  SPOL(2, 0, 1) SPOL(2, 0, 2) SPOL(2, 0, 3) SPOL(2, 0, 4)
+  SPOL(2, 1, 1) SPOL(2, 3, 3)
+  SPOL(1, 0, 0) SPOL(1, 1, 1) SPOL(1, 0, 3)
   STILE(256, 2, 1)
   return 0;
 }
