@@ -178,5 +178,7 @@ int main() {
   SPOL(2, 1, 1) SPOL(2, 3, 3)
   SPOL(1, 0, 0) SPOL(1, 1, 1) SPOL(1, 0, 3)
   STILE(256, 2, 1)
+  // block size at one float4 group per lane (round 3): does a 512- or 1024-thread block buy what two groups per lane buy?
+  STILE(512, 1, 1) STILE(1024, 1, 1) STILE(512, 2, 1) STILE(128, 2, 1) STILE(128, 4, 1)
   return 0;
 }
