@@ -129,3 +129,19 @@ def test_polynomial_entries_refuse_a_misaligned_coefficient_table():
     # alignment (with NULL images the first complaint is the image pointer, never "aligned")
     three = ctypes.c_void_p(4096 + 2)
     assert lib.curl_trispace_fwd_f32(fake, three, fake, 1, 8, 8, 35, 0, None) == -2 and b"4-byte" in lib.curl_last_error()
+
+
+def test_public_header_compiles_as_c99_and_cxx(tmp_path):
+    """include/curl_hip.h is the boundary a cgo / JNI / ctypes maintainer reads: plain C, no torch or HIP types."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not present")
+    src = tmp_path / "h.c"
+    src.write_text('#include "curl_hip.h"\nint main(void) { return curl_version() > 0 ? 0 : CURL_K_UNEVEN(16, 14) + (int)CURL_F_WS_READY; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-I", inc, "-o", str(tmp_path / "c.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-x", "c++", "-c", str(src), "-I", inc, "-o", str(tmp_path / "cc.o")])
+    txt = open(HEADER).read()
+    assert "torch" not in txt.lower().replace("pytorch's caching allocator", "") or "at::" not in txt
+    assert "hip/hip_runtime" not in txt
