@@ -57,6 +57,7 @@ VARIANTS = {
     "nolazy": ["-DCURL_NO_LAZY_SELECT"],  # the Lab converters' threshold selects always executed (default: skipped by waves that need none)
     "nomem_inline": ["-DCURL_NOMEM_INLINE"],  # the no-memory diagnostics branch left to the compiler (ten v_mov splats on the product path)
     "mask_last": ["-DCURL_MASK_LOAD_LAST"],  # the mask's load behind the three plane loads (where the compiler put it once the bytes were one dword)
+    "addr64": ["-DCURL_ADDR64"],  # streaming kernels: pointer + 64-bit lane offset (default: SGPR plane base + 32-bit byte offset)
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
