@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/curl_hip.h"
 #include "curl_math_bwd.h"

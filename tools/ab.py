@@ -52,6 +52,12 @@ def main():
     loss_nb = libs["A"].curl_loss_terms_scratch_bytes(B, H, W)
     loss_scratch = torch.empty(max(4, loss_nb) // 4, device=dev)
 
+    w4 = torch.tensor([1.0, 1e-3, 1.0, 1.0], device=dev)
+    gLp = torch.rand(B, 1, H, W, device=dev)
+    psnr_nb = libs["A"].curl_psnr_scratch_bytes(B, H, W)
+    psnr_scratch = torch.empty(max(4, psnr_nb) // 4, device=dev)
+    bytes_ = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev)
+
     def run(lib, flags):
         cnt[0] += 1
         img = imgs[cnt[0] & 1]
@@ -65,6 +71,16 @@ def main():
         elif what == "loss_fwd":
             rc = lib.curl_loss_terms_f32(img.data_ptr(), imgs[1 - (cnt[0] & 1)].data_ptr(), mask.data_ptr(), 1, loss_sums.data_ptr(),
                                          loss_L[0].data_ptr(), loss_L[1].data_ptr(), loss_scratch.data_ptr(), loss_nb, B, H, W, stream)
+        elif what == "loss_bwd":
+            rc = lib.curl_loss_terms_bwd_f32(img.data_ptr(), imgs[1 - (cnt[0] & 1)].data_ptr(), mask.data_ptr(), 1, w4.data_ptr(),
+                                             gLp.data_ptr(), out.data_ptr(), B, H, W, stream)
+        elif what == "psnr":
+            rc = lib.curl_psnr_f32(img.data_ptr(), imgs[1 - (cnt[0] & 1)].data_ptr(), mask.data_ptr(), 1, reg.data_ptr(),
+                                   psnr_scratch.data_ptr(), psnr_nb, B, H, W, 1.0, stream)
+        elif what == "to_u8":
+            rc = lib.curl_f32chw_to_u8hwc(img.data_ptr(), bytes_.data_ptr(), B, H, W, stream)
+        elif what == "from_u8":
+            rc = lib.curl_u8hwc_to_f32chw(bytes_.data_ptr(), out.data_ptr(), B, H, W, 3, stream)
         elif what == "rgb2lab":
             rc = lib.curl_rgb2lab_f32(img.data_ptr(), out.data_ptr(), B, H, W, flags, stream)
         elif what == "adjust_rgb":
@@ -81,7 +97,7 @@ def main():
         assert rc == 0, rc
 
     extra = {"A": int(os.environ.get("FLAGS_A", "0"), 0), "B": int(os.environ.get("FLAGS_B", "0"), 0)}  # e.g. 0x200 = U=2
-    full_only = what in ("layer_bwd", "loss_fwd") or os.environ.get("FULL_ONLY")  # FULL_ONLY=1: skip the arithmetic-only (no-memory) legs
+    full_only = what in ("layer_bwd", "loss_fwd", "loss_bwd", "psnr", "to_u8", "from_u8") or os.environ.get("FULL_ONLY")  # FULL_ONLY=1: skip the arithmetic-only (no-memory) legs
     variants = [(k, d) for d in ((0,) if full_only else (0, _lib.F_DIAG_NO_MEM)) for k in ("A", "B")]
     LAUNCHES = int(os.environ.get("LAUNCHES", 100))  # per timed window
     times = {v: [] for v in variants}
