@@ -58,6 +58,7 @@ VARIANTS = {
     "nomem_inline": ["-DCURL_NOMEM_INLINE"],  # the no-memory diagnostics branch left to the compiler (ten v_mov splats on the product path)
     "mask_last": ["-DCURL_MASK_LOAD_LAST"],  # the mask's load behind the three plane loads (where the compiler put it once the bytes were one dword)
     "addr64": ["-DCURL_ADDR64"],  # streaming kernels: pointer + 64-bit lane offset (default: SGPR plane base + 32-bit byte offset)
+    "pow24_direct": ["-DCURL_POW24_DIRECT"],  # fused stages: u^2.4 as 2^(2.4 log2 u) (default: u*u * 2^(0.4 log2 u)); -1 % and one test pixel over 1e-5
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
     "poly1_pk": ["-DCURL_PRIO_POLY=1", "-DCURL_USE_PK", "-DCURL_PRIO_PK=1"],
