@@ -213,3 +213,56 @@ def test_one_frame_10000x10000_vs_oracle_bands(ops, dev):
     slab = torch.zeros_like(img)
     ops.curl_layer_forward_rows(img, mask, L, R, Hk, (8750, 10000), slab)
     assert torch.equal(slab[:, :, 8750:], out[:, :, 8750:]) and not slab[:, :, :8750].any()
+
+
+def test_one_image_at_the_api_limit_of_2_to_30_pixels(ops, dev):
+    """check_img admits H*W <= 2^30 pixels, and the streaming kernels rely on it: a lane's BYTE offset inside a plane is 32-bit
+    (stream.inc at(): 2^28 float4 groups x 16 B, or 2^30 floats x 4 B on the scalar path).  One 32768 x 32768 image
+    (12.9 GB per tensor): the last rows -- the largest offsets -- and the first must equal the same rows processed as an
+    image of their own (the path is pixel-wise; the knots are the same), float4 and scalar kernels, layer / PSNR / byte edge;
+    one pixel more is refused."""
+    H = W = 32768
+    g = torch.Generator(device=dev).manual_seed(30)
+    buf = torch.empty(3 * H * W + 1, device=dev)
+    buf.uniform_(generator=g)
+    img = buf[:-1].view(1, 3, H, W)
+    mask = torch.rand(1, 1, H, W, device=dev, generator=g) > 0.2
+    L, R, Hk = (torch.randn(1, n, device=dev, generator=g) * 0.1 for n in (48, 48, 64))
+    out, reg = ops.curl_layer_forward(img, mask, L, R, Hk)
+    bands = (slice(0, 8), slice(H - 8, H))
+
+    def alone(x, rows):
+        return x[:, :, rows].contiguous()
+
+    for rows in bands:
+        o1, _ = ops.curl_layer_forward(alone(img, rows), alone(mask, rows), L, R, Hk)
+        assert torch.equal(o1, out[:, :, rows]), rows
+    u8 = ops.f32chw_to_u8hwc(out)
+    for rows in bands:
+        assert torch.equal(ops.f32chw_to_u8hwc(alone(out, rows)), u8[:, rows]), rows
+    del u8
+    # PSNR of (out, img) under the mask: the reduction walks every block of the 2^30 pixels; against torch on the GPU
+    p = ops.psnr_per_image(out, img, mask)
+    m = mask.float()
+    se = torch.zeros((), dtype=torch.float64, device=dev)
+    for c in range(3):  # channel by channel: no 12.9 GB temporaries
+        se += (((out[0, c].clamp(0, 1) - img[0, c].clamp(0, 1)) * m[0, 0]) ** 2).sum(dtype=torch.float64)
+    want = 10.0 * torch.log10(1.0 / (se / (3.0 * m.sum(dtype=torch.float64))))
+    assert abs(float(p[0]) - float(want)) <= 1e-4 * abs(float(want))
+    del m
+    # scalar kernels: the same pixels from a base pointer 4 bytes off (every float4 test fails -> VEC = 1, i up to 2^30 - 1)
+    first = img.flatten()[0].clone()
+    view = buf[1:].view(1, 3, H, W)
+    assert view.data_ptr() % 16 == 4
+    del out
+    o_s, _ = ops.curl_layer_forward(view, mask, L, R, Hk)
+    for rows in bands:
+        small = torch.empty(3 * 8 * W + 1, device=dev)[1:].view(1, 3, 8, W)  # the band alone, off the boundary as well
+        small.copy_(view[:, :, rows])
+        o1, _ = ops.curl_layer_forward(small, alone(mask, rows), L, R, Hk)
+        assert torch.equal(o1, o_s[:, :, rows]), rows
+    assert float(first) == float(buf[0])
+    del o_s, view, img, buf, mask
+    torch.cuda.empty_cache()
+    with pytest.raises(ValueError, match="2\\^30"):  # CURL_E_SHAPE
+        ops.curl_layer_forward(torch.empty(1, 3, 1, 2 ** 30 + 1, device=dev), None, L, R, Hk)
