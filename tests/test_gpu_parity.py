@@ -1248,6 +1248,27 @@ def test_xcd_contiguous_tile_mapping_is_the_same_result(ops, dev):
         ops.rgb2lab(img, flags=3 << 13)
 
 
+def test_resident_workgroup_cap_is_the_same_result(ops, dev):
+    """Large launches of the light operators run one float4 group per lane at Op::kResident workgroups per CU (unused LDS
+    reserved at launch); CURL_F_TUNE_OCC = 1 asks for the uncapped library tile shape, 2..7 for k.  Only
+    the schedule changes: identical bits above and below the size where the default switches (22 tiles per CU)."""
+    OFF, K2, K7 = 1 << 19, 2 << 19, 7 << 19
+    g = torch.Generator().manual_seed(19)
+    for B, H, W in ((6, 1000, 1500), (1, 512, 768)):   # 8 790 tiles: capped by default / 384: not
+        img = torch.rand(B, 3, H, W, generator=g).to(dev)
+        mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+        L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+        for f in (OFF, K2, K7, K2 | (2 << 8)):
+            assert torch.equal(ops.rgb2lab(img), ops.rgb2lab(img, flags=f)), (B, f)
+            assert torch.equal(ops.hsv2rgb(img), ops.hsv2rgb(img, flags=f)), (B, f)
+            a, ra = ops.adjust_rgb(img, R)
+            b, rb = ops.adjust_rgb(img, R, flags=f)
+            assert torch.equal(a, b) and torch.equal(ra, rb), (B, f)
+            assert torch.equal(ops.lab_stage(img, mask, L)[0], ops.lab_stage(img, mask, L, flags=f)[0]), (B, f)
+            assert torch.equal(ops.hsv_stage(img, mask, Hk)[0], ops.hsv_stage(img, mask, Hk, flags=f)[0]), (B, f)
+            assert torch.equal(ops.curl_layer_forward(img, mask, L, R, Hk)[0], ops.curl_layer_forward(img, mask, L, R, Hk, flags=f)[0])
+
+
 def test_layer_forward_and_backward_replay_from_a_hip_graph(ops, dev):
     """The library only enqueues on the stream it is handed (no synchronisation, no allocation of its own), so its calls
     can be captured into a HIP graph and replayed: the launch-bound shapes (a training crop batch is 22 us forward + 26 us

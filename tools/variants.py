@@ -58,6 +58,10 @@ VARIANTS = {
     "nomem_inline": ["-DCURL_NOMEM_INLINE"],  # the no-memory diagnostics branch left to the compiler (ten v_mov splats on the product path)
     "mask_last": ["-DCURL_MASK_LOAD_LAST"],  # the mask's load behind the three plane loads (where the compiler put it once the bytes were one dword)
     "addr64": ["-DCURL_ADDR64"],  # streaming kernels: pointer + 64-bit lane offset (default: SGPR plane base + 32-bit byte offset)
+    "aux_res2": ["-DCURL_RES_PSNR=2", "-DCURL_RES_EGRESS=2", "-DCURL_RES_INGRESS=2", "-DCURL_RES_LOSS=2", "-DCURL_RES_LOSS_BWD=2"],  # PSNR / byte edges / loss terms at 2 workgroups per CU (default: edges 4, the others uncapped)
+    "aux_res4": ["-DCURL_RES_PSNR=4", "-DCURL_RES_EGRESS=4", "-DCURL_RES_INGRESS=4", "-DCURL_RES_LOSS=4", "-DCURL_RES_LOSS_BWD=4"],  # PSNR / byte edges / loss terms at 4 workgroups per CU (default: edges 4, the others uncapped)
+    "aux_res6": ["-DCURL_RES_PSNR=6", "-DCURL_RES_EGRESS=6", "-DCURL_RES_INGRESS=6", "-DCURL_RES_LOSS=6", "-DCURL_RES_LOSS_BWD=6"],  # PSNR / byte edges / loss terms at 6 workgroups per CU (default: edges 4, the others uncapped)
+    "aux_res0": ["-DCURL_RES_EGRESS=0", "-DCURL_RES_INGRESS=0"],  # the byte edges uncapped (before exp27g)
     "pow24_direct": ["-DCURL_POW24_DIRECT"],  # fused stages: u^2.4 as 2^(2.4 log2 u) (default: u*u * 2^(0.4 log2 u)); -1 % and one test pixel over 1e-5
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
