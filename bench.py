@@ -28,7 +28,10 @@ sys.path.insert(0, ROOT)
 
 H_IMG, W_IMG = 1000, 1500
 CLOCK_SETTLE_LAUNCHES = 150
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# the path's own 3-planes-in / 3-planes-out copy at its best launch shape (2-3 waves per SIMD; 6.17 at full occupancy):
+# tools/ubench/occ.hip, profiles/r03/exp27c_occupancy_copy_probe.log
+COPY_CEILING_GBPS = 6585.0
 
 
 def disk_mask(B, H, W, device):
@@ -566,7 +569,7 @@ def main():
         # the PMC pass was taken at bs32 on the forward workloads
         traffic, traffic_src = load_traffic(w["frag"]) if B == 32 and name not in CONFIG5 else (None, None)
         hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-               "frac_of_measured_copy_ceiling_6290": gbps / 6290.0}
+               "frac_of_measured_copy_ceiling_6585": gbps / COPY_CEILING_GBPS}
         valu = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,
                 "flop_per_px": w["flop_px"]}
         roof = dict(hbm if w["bound"] == "hbm" else valu)
