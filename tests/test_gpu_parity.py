@@ -1267,6 +1267,8 @@ def test_resident_workgroup_cap_is_the_same_result(ops, dev):
             assert torch.equal(ops.lab_stage(img, mask, L)[0], ops.lab_stage(img, mask, L, flags=f)[0]), (B, f)
             assert torch.equal(ops.hsv_stage(img, mask, Hk)[0], ops.hsv_stage(img, mask, Hk, flags=f)[0]), (B, f)
             assert torch.equal(ops.curl_layer_forward(img, mask, L, R, Hk)[0], ops.curl_layer_forward(img, mask, L, R, Hk, flags=f)[0])
+            C = torch.exp(L[:, :16])
+            assert torch.equal(ops.apply_curve(img, C, None, 2, 0, flags=0)[0], ops.apply_curve(img, C, None, 2, 0, flags=f)[0]), (B, f)
 
 
 def test_layer_forward_and_backward_replay_from_a_hip_graph(ops, dev):
