@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 H_IMG, W_IMG = 1000, 1500
 CLOCK_SETTLE_LAUNCHES = 150
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# the path's own 3-planes-in / 3-planes-out copy at its best launch shape (2-3 waves per SIMD; 6.17 at full occupancy):
-# tools/ubench/occ.hip, profiles/r03/exp27c_occupancy_copy_probe.log
+# the path's own 3-planes-in / 3-planes-out copy at its best launch shape (2 waves per SIMD: 174.0-174.9 us on two cards;
+# 6.17 TB/s at full occupancy): tools/ubench/occ.hip, profiles/r03/exp27c_occupancy_copy_probe.log, exp27i_residency.log
 COPY_CEILING_GBPS = 6585.0
 
 

@@ -78,8 +78,8 @@ enum {
                                       workgroups round-robin, each own one contiguous eighth of an image's tiles) */
 #define CURL_F_TUNE_XCD_MASK 0x6000u
 #define CURL_F_TUNE_OCC_SHIFT 19   /* bits 19..21: resident 256-thread workgroups per CU of the f32 streaming kernels (= waves per
-                                     SIMD), held down by reserving 160 KB / k of unused LDS: 0 = library default per operator
-                                     (large launches of the light operators run at 3-7), 1 = no cap,
+                                     SIMD), held down by reserving unused LDS (floor(128 / k) granules of 1 280 bytes): 0 = library default per operator
+                                     (large launches of the light operators run at 2-6), 1 = no cap,
                                      2..7 = k */
 #define CURL_F_TUNE_OCC_MASK 0x380000u
 #define CURL_F_TUNE_NO_NT 0x8000u     /* plain loads/stores instead of the default non-temporal ones */

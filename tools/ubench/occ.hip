@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_tile(const v4f* __restrict__ in, v4f* _
 template <int U>
 static void sweep(v4f** in, v4f* out, unsigned n, int B, size_t bytes, hipEvent_t e0, hipEvent_t e1) {
   hipFuncSetAttribute((const void*)k_tile<U>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const unsigned lds[] = {0, 16384, 20480, 23296, 27136, 32768, 40960, 54528, 65536, 81920, 163840};
+  const unsigned lds[] = {0, 16384, 20480, 23296, 27136, 32768, 36864, 40960, 45056, 49152, 54528, 65536, 81920, 163840};
   for (unsigned l : lds) {
     int nb = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<U>, 256, l);
@@ -48,6 +48,36 @@ static void sweep(v4f** in, v4f* out, unsigned n, int B, size_t bytes, hipEvent_
   }
 }
 
+// how many workgroups REALLY share a CU for a given reservation: every workgroup spins a fixed number of clock ticks, so the
+// launch takes (workgroups per CU / resident) x spin
+__global__ __launch_bounds__(256) void k_spin(unsigned long long ticks, unsigned* sink) {
+  extern __shared__ float unused_lds[];
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (sink && threadIdx.x == 0 && blockIdx.x == 0xffffffffu) *sink = 1;
+}
+static void residency(hipEvent_t e0, hipEvent_t e1) {
+  hipFuncSetAttribute((const void*)k_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int cus = 256;
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  const int per_cu = 48;
+  const unsigned long long ticks = 2000000ull;  // 20 ms at the 100 MHz constant clock
+  float base = 0;
+  for (unsigned l = 0; l <= 163840; l += (l < 81920 ? 4096 : 16384)) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spin, 256, l);
+    hipLaunchKernelGGL(k_spin, dim3(cus * per_cu), dim3(256), l, 0, 1000ull, nullptr);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_spin, dim3(cus * per_cu), dim3(256), l, 0, ticks / per_cu, nullptr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (l == 0) base = ms;
+    printf("spin  dynamic LDS %6u B  runtime says %2d per CU  %7.2f ms  -> resident = %.2f x the no-reservation case\n", l, nb, ms, base / ms);
+    fflush(stdout);
+  }
+}
+
 int main() {
   const int B = 32, H = 1000, W = 1500;
   const unsigned n = H * W / 4;
@@ -56,6 +86,7 @@ int main() {
   for (auto& p : in) { hipMalloc(&p, bytes); hipMemset(p, 0x3c, bytes); }
   hipMalloc(&out, bytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  residency(e0, e1);
   sweep<1>(in, out, n, B, bytes, e0, e1);
   sweep<2>(in, out, n, B, bytes, e0, e1);
   sweep<4>(in, out, n, B, bytes, e0, e1);

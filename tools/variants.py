@@ -61,6 +61,8 @@ VARIANTS = {
     "aux_res2": ["-DCURL_RES_PSNR=2", "-DCURL_RES_EGRESS=2", "-DCURL_RES_INGRESS=2", "-DCURL_RES_LOSS=2", "-DCURL_RES_LOSS_BWD=2"],  # PSNR / byte edges / loss terms at 2 workgroups per CU (default: edges 4, the others uncapped)
     "aux_res4": ["-DCURL_RES_PSNR=4", "-DCURL_RES_EGRESS=4", "-DCURL_RES_INGRESS=4", "-DCURL_RES_LOSS=4", "-DCURL_RES_LOSS_BWD=4"],  # PSNR / byte edges / loss terms at 4 workgroups per CU (default: edges 4, the others uncapped)
     "aux_res6": ["-DCURL_RES_PSNR=6", "-DCURL_RES_EGRESS=6", "-DCURL_RES_INGRESS=6", "-DCURL_RES_LOSS=6", "-DCURL_RES_LOSS_BWD=6"],  # PSNR / byte edges / loss terms at 6 workgroups per CU (default: edges 4, the others uncapped)
+    "aux_res3": ["-DCURL_RES_PSNR=3", "-DCURL_RES_EGRESS=3", "-DCURL_RES_INGRESS=3", "-DCURL_RES_LOSS=3", "-DCURL_RES_LOSS_BWD=3"],
+    "aux_res5": ["-DCURL_RES_PSNR=5", "-DCURL_RES_EGRESS=5", "-DCURL_RES_INGRESS=5", "-DCURL_RES_LOSS=5", "-DCURL_RES_LOSS_BWD=5"],
     "aux_res0": ["-DCURL_RES_EGRESS=0", "-DCURL_RES_INGRESS=0"],  # the byte edges uncapped (before exp27g)
     "pow24_direct": ["-DCURL_POW24_DIRECT"],  # fused stages: u^2.4 as 2^(2.4 log2 u) (default: u*u * 2^(0.4 log2 u)); -1 % and one test pixel over 1e-5
     "poly1": ["-DCURL_PRIO_POLY=1"],
