@@ -23,6 +23,7 @@ F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
 F_DIAG_SKIP_PREP = 0x20000
 F_WS_READY = 0x40000
+F_MASK_FIRST = 0x400000  # foreground masks: fully masked-out wavefronts never read their pixels
 MAX_KNOTS = 256
 
 _c_f = ctypes.c_void_p  # device pointers travel as integers

@@ -15,11 +15,12 @@ class _CurlLayerFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # under autocast: float32 in, autocast off
-    def forward(ctx, img, mask, L, R, H):
-        out, reg, ws = ops.curl_layer_forward(img, mask, L, R, H, return_workspace=True)
+    def forward(ctx, img, mask, L, R, H, flags=0):
+        out, reg, ws = ops.curl_layer_forward(img, mask, L, R, H, flags=flags, return_workspace=True)
         # the knot workspace (exp'd knots, collapsed curves: 768 B per image) rides along: the backward skips its prep launch
         ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous(), ws)
         ctx.mask = mask
+        ctx.flags = flags
         return out, reg
 
     @staticmethod
@@ -28,18 +29,23 @@ class _CurlLayerFn(torch.autograd.Function):
         img, L, R, H, ws = ctx.saved_tensors
         need_img = ctx.needs_input_grad[0]
         g_img, gL, gR, gH = ops.curl_layer_backward(img, ctx.mask, L, R, H, grad_out.contiguous(), grad_reg, need_img,
-                                                    workspace=ws)
-        return g_img, None, gL, gR, gH
+                                                    workspace=ws, flags=ctx.flags)
+        return g_img, None, gL, gR, gH, None
 
 
 class CURLLayer(nn.Module):
     """model.py:121-176.  Same constructor arguments, same forward signature and returns.
     `paper_pwl=True` (not in the reference) evaluates the curves as the paper's clamped piecewise-linear
-    interpolation of the knots (CURL_F_PWL: knots in LDS) instead of the reference's affine form; inference only."""
+    interpolation of the knots (CURL_F_PWL: knots in LDS) instead of the reference's affine form; inference only.
+    `foreground_masks=True` (not in the reference either) tells the kernel that the bool / uint8 masks it will see have
+    sizeable empty regions (data.py:186-190: segmentation masks): wavefronts test their mask bytes before asking for their
+    pixels and never read fully masked-out tiles (CURL_F_MASK_FIRST: -7 % at 70 % coverage, -25 % at 40 %, +0.9 % on an
+    all-ones mask; the same results bit for bit)."""
 
-    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64, paper_pwl=False):
+    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64, paper_pwl=False, foreground_masks=False):
         super().__init__()
         self.paper_pwl = paper_pwl
+        self.flags = ops.F_MASK_FIRST if foreground_masks else 0
         self.num_lab_points = num_lab_points
         self.num_rgb_points = num_rgb_points
         self.num_hsv_points = num_hsv_points
@@ -61,10 +67,10 @@ class CURLLayer(nn.Module):
         if self.paper_pwl:
             if needs_grad:
                 raise NotImplementedError("curl_amd: paper_pwl has no backward (the reference's curves are the affine form)")
-            return ops.curl_layer_forward(img, mask, L, R, H, flags=ops.F_PWL)
+            return ops.curl_layer_forward(img, mask, L, R, H, flags=ops.F_PWL | self.flags)
         if needs_grad:
-            return _CurlLayerFn.apply(img, mask, L, R, H)
-        return ops.curl_layer_forward(img, mask, L, R, H)
+            return _CurlLayerFn.apply(img, mask, L, R, H, self.flags)
+        return ops.curl_layer_forward(img, mask, L, R, H, flags=self.flags)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ from types import SimpleNamespace
 import torch
 
 from . import _lib
-from ._lib import F_EXACT_ORDER, F_PWL, MASK_F32, MASK_NONE, MASK_U8
+from ._lib import F_EXACT_ORDER, F_MASK_FIRST, F_PWL, MASK_F32, MASK_NONE, MASK_U8
 
 
 def _empty_ok(mask_arg=None):
@@ -365,7 +365,7 @@ def trispace_forward_rows(img, coeffs, rows, out, residual_only=False):
 
 
 @_one_device
-def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True, workspace=None):
+def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True, workspace=None, flags=0):
     """Backward of curl_layer_forward (what autograd would run through model.py:137-176).
     -> (grad_img or None, grad_L, grad_R, grad_H).
     workspace: the tensor curl_layer_forward(..., return_workspace=True) returned for the SAME knots (CURL_F_WS_READY)."""
@@ -387,11 +387,11 @@ def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_i
     g_img = torch.empty_like(img) if need_grad_img else None
     gL, gR, gH = torch.empty_like(Lc), torch.empty_like(Rc), torch.empty_like(Hc)
     ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], img.device)
-    bflags = 0
+    bflags = flags & F_MASK_FIRST  # the one forward flag that means something here
     if workspace is not None:
         if workspace.device != img.device or workspace.dtype != torch.float32 or workspace.numel() * 4 < nbytes:
             raise ValueError("workspace is not the tensor curl_layer_forward returned for this batch")
-        ws, bflags = workspace, _lib.F_WS_READY
+        ws, bflags = workspace, bflags | _lib.F_WS_READY
     sbytes = lib.curl_layer_bwd_scratch_bytes(B, Hh, W)
     scratch = torch.empty(sbytes // 4, dtype=torch.float32, device=img.device)
     rc = lib.curl_layer_bwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(),

@@ -83,6 +83,11 @@ enum {
                                      2..7 = k */
 #define CURL_F_TUNE_OCC_MASK 0x380000u
 #define CURL_F_TUNE_NO_NT 0x8000u     /* plain loads/stores instead of the default non-temporal ones */
+#define CURL_F_MASK_FIRST 0x400000u /* bool / uint8 FOREGROUND masks (curl_layer_fwd(_slab)_f32, curl_lab_stage_f32,
+                                      curl_hsv_stage_f32, curl_layer_bwd_f32): a wavefront first waits for its mask bytes
+                                      and, where all of them are zero, never reads its pixels.  Forward: +0.5 ... +0.8 % on an
+                                      all-ones mask, -7 % at 70 % coverage, -25 % at 40 %.  Same results
+                                      bit for bit.  Ignored where it does not apply (other mask kinds, scalar kernels). */
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */
 

@@ -469,3 +469,56 @@ def test_backward_reuses_the_forward_workspace(ops, dev):
     o, r = layer(x, mask, Lg, Rg, Hg)
     ((o * w).sum() + (r * wr).sum()).backward()
     assert torch.equal(x.grad, a[0]) and torch.equal(Lg.grad, a[1]) and torch.equal(Rg.grad, a[2]) and torch.equal(Hg.grad, a[3])
+
+
+def test_foreground_masks_skip_masked_out_wavefronts(ops, dev):
+    """Segmentation masks (data.py:186-190) leave whole wavefronts (256 consecutive pixels) masked out.  The backward skips
+    their arithmetic (every gradient there is an exact zero); with CURL_F_MASK_FIRST forward and backward also wait for
+    the mask and never read those pixels.  Same numbers either way -- against the flag-less call, against the float-mask
+    path (which has neither shortcut), against autograd through the oracle, and through CURLLayer(foreground_masks=True)."""
+    import curl_oracle as O
+    from curl_amd import model
+    g = torch.Generator().manual_seed(190)
+    B, H, W = 2, 24, 1024
+    img = torch.rand(B, 3, H, W, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.3
+    mask[:, :, 5:14] = False          # nine rows of four wavefronts each: fully masked out
+    mask[0, :, 14, :512] = False      # ... and half a row
+    mask[1, :, :3] = True             # fully inside the foreground
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (48, 48, 64))
+    w = torch.randn(B, 3, H, W, generator=g)
+    wr = torch.rand(B, generator=g)
+    d = [t.to(dev) for t in (img, mask, L, R, Hk, w, wr)]
+    F = ops.F_MASK_FIRST
+    out0, reg0 = ops.curl_layer_forward(*d[:5])
+    out1, reg1 = ops.curl_layer_forward(*d[:5], flags=F)
+    assert torch.equal(out0, out1) and torch.equal(reg0, reg1)
+    assert torch.equal(ops.lab_stage(d[0], d[1], d[2])[0], ops.lab_stage(d[0], d[1], d[2], flags=F)[0])
+    assert torch.equal(ops.hsv_stage(d[0], d[1], d[4])[0], ops.hsv_stage(d[0], d[1], d[4], flags=F)[0])
+    ref, _ = O.curl_layer(img, mask.float(), L, R, Hk)
+    assert float((out1.cpu() - ref).abs().max()) <= 1e-5
+    a = ops.curl_layer_backward(*d[:5], d[5], d[6])
+    b = ops.curl_layer_backward(*d[:5], d[5], d[6], flags=F)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert not a[0][:, :, 5:14].any()
+    f = ops.curl_layer_backward(d[0], d[1].float(), *d[2:5], d[5], d[6])   # general path: no shortcut of either kind
+    assert float((a[0] - f[0]).abs().max()) <= 2e-6 * float(f[0].abs().max())
+    for x, y in zip(a[1:], f[1:]):
+        assert rel(x, y) <= 1e-5
+    # autograd through the oracle
+    x = img.clone().requires_grad_(True)
+    Lg, Rg, Hg = (t.clone().requires_grad_(True) for t in (L, R, Hk))
+    o, r = O.curl_layer(x, mask.float(), Lg, Rg, Hg)
+    ((o * w).sum() + (r * wr).sum()).backward()
+    for got, want in zip(a[1:], (Lg.grad, Rg.grad, Hg.grad)):
+        assert rel(got, want) <= 1e-3
+    dd = (a[0].cpu() - x.grad).abs()
+    assert float(torch.quantile(dd.flatten(), 0.995)) <= 3e-4 * float(x.grad.abs().max())
+    # the module route
+    layer = model.CURLLayer(foreground_masks=True).to(dev)
+    xs = d[0].clone().requires_grad_(True)
+    Ld, Rd, Hd = (t.clone().requires_grad_(True) for t in d[2:5])
+    o, r = layer(xs, d[1], Ld, Rd, Hd)
+    ((o * d[5]).sum() + (r * d[6]).sum()).backward()
+    assert torch.equal(o, out0) and torch.equal(xs.grad, a[0]) and torch.equal(Ld.grad, a[1]) and torch.equal(Hd.grad, a[3])

@@ -33,6 +33,11 @@ def main():
     imgs = [lo + (1.0 - lo) * torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
     out = torch.empty_like(imgs[0])
     mask = torch.ones(B, 1, H, W, dtype=torch.uint8, device=dev)
+    if os.environ.get("MASK") == "disk":  # bench.py's disk: ~70 % coverage, whole wavefronts inside and outside
+        yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        r2 = ((yy - H / 2) / (H / 2)) ** 2 + ((xx - W / 2) / (W / 2)) ** 2
+        mask = (r2 <= float(os.environ.get("DISK_R2", 0.9))).to(torch.uint8).expand(B, 1, H, W).contiguous()
+        print("mask coverage", float(mask.float().mean()))
     L, R, Hk = (torch.randn(B, n, device=dev) * 0.1 for n in (48, 48, 64))
     poly = torch.randn(B, 3, 3, 126, device=dev) * 0.2
     reg = torch.empty(B, device=dev)
@@ -67,7 +72,7 @@ def main():
         elif what == "layer_bwd":
             rc = lib.curl_layer_bwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
                                         gout.data_ptr(), 0, gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
-                                        ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, 0, stream)
+                                        ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, flags & 0x400000, stream)
         elif what == "loss_fwd":
             rc = lib.curl_loss_terms_f32(img.data_ptr(), imgs[1 - (cnt[0] & 1)].data_ptr(), mask.data_ptr(), 1, loss_sums.data_ptr(),
                                          loss_L[0].data_ptr(), loss_L[1].data_ptr(), loss_scratch.data_ptr(), loss_nb, B, H, W, stream)
