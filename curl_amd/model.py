@@ -247,9 +247,11 @@ class GCURLNet(nn.Module):
     network download (model.py:189); here the head width is what the layer consumes
     (num_lab_points + num_rgb_points + num_hsv_points) and the backbone is injectable.
     `encoder_size` (optional): the encoder sees the image resized to this square while the curves are
-    applied at full resolution -- the low-res-encode / full-res-apply shape of infer.py:32-44."""
+    applied at full resolution -- the low-res-encode / full-res-apply shape of infer.py:32-44.
+    `foreground_masks`: see CURLLayer."""
 
-    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64, backbone=None, encoder_size=None):
+    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64, backbone=None, encoder_size=None,
+                 foreground_masks=False):
         super().__init__()
         self.num_lab_points = num_lab_points
         self.num_rgb_points = num_rgb_points
@@ -264,7 +266,7 @@ class GCURLNet(nn.Module):
             backbone.classifier = nn.Sequential(nn.Linear(backbone.classifier.in_features, n_out))  # model.py:190-192
         self.backbone = backbone
         self.encoder_size = encoder_size
-        self.curllayer = CURLLayer(num_lab_points, num_rgb_points, num_hsv_points)
+        self.curllayer = CURLLayer(num_lab_points, num_rgb_points, num_hsv_points, foreground_masks=foreground_masks)
 
     def predict_knots(self, img):
         x = img

@@ -73,7 +73,7 @@ def apply_row_slab(layer, img, mask, L, R, H, rank, world, out=None):
     if img.is_cuda and isinstance(layer, CURLLayer) and not needs_grad:
         from . import ops
         L, R, H = L[:, :layer.num_lab_points], R[:, :layer.num_rgb_points], H[:, :layer.num_hsv_points]  # model.py:153,159,165
-        flags = ops.F_PWL if layer.paper_pwl else 0  # CURLLayer(paper_pwl=True): the non-parity option
+        flags = (ops.F_PWL if layer.paper_pwl else 0) | layer.flags  # CURLLayer(paper_pwl=True): the non-parity option
         _, reg = ops.curl_layer_forward_rows(img, mask, L, R, H, (r0, r1), out, flags=flags)
         return out, reg, (r0, r1)
     sub = img[:, :, r0:r1, :].contiguous()
