@@ -51,6 +51,7 @@ static int hip_fail(hipError_t e, const char* where) {
 #define WS_COEF 0
 #define WS_REG 20
 #define WS_MASKED 24
+#define WS_FLAG 28  // 1.0f: the image's bool / uint8 mask has sizeable empty regions (knots_prep_kernel's sample)
 #define WS_KNOTS 32
 #define MAX_CURVES 10
 
@@ -71,6 +72,10 @@ struct PrepArgs {
   float* ws;
   float* reg_out;  // nullable, [B], assigned
   unsigned stride;
+  // bool / uint8 mask of the images as dwords (4 pixels each), or NULL: 1 024 of them per image are sampled while the knots
+  // are on their way, and ws[WS_FLAG] says whether >= 1/16 of them were entirely zero
+  const unsigned* mask_dw;
+  unsigned mask_dwords;  // per image
 };
 
 // One workgroup per image.  exp in float64 (rounded once to float32: the best estimate of torch.exp's
@@ -78,22 +83,39 @@ struct PrepArgs {
 __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
   __shared__ float sC[MAX_CURVES * CURL_MAX_KNOTS];
   __shared__ float sReg[MAX_CURVES];
+#if defined(CURL_MASK_SAMPLE)
+  __shared__ unsigned sZero[4];
+#endif
   const unsigned b = blockIdx.x;
   float* ws = a.ws + (size_t)b * a.stride;
+
   int seg_off[4];
   seg_off[0] = 0;
 #pragma unroll
   for (int s = 0; s < 3; ++s) seg_off[s + 1] = seg_off[s] + (a.raw[s] ? KP_TOTAL(a.K[s], a.ncurves[s]) : 0);
   const int n_total = seg_off[3];
   for (int i = threadIdx.x; i < n_total; i += 256) {
-    int s = (i >= seg_off[2]) ? 2 : (i >= seg_off[1]) ? 1 : 0;
-    int local = i - seg_off[s];
-    int per_img = KP_TOTAL(a.K[s], a.ncurves[s]);
-    float r = a.raw[s][(size_t)b * per_img + local];
+    const int s = (i >= seg_off[2]) ? 2 : (i >= seg_off[1]) ? 1 : 0;
+    const int local = i - (s == 2 ? seg_off[2] : s == 1 ? seg_off[1] : seg_off[0]);
+    const int per_img = s == 2 ? KP_TOTAL(a.K[2], a.ncurves[2]) : s == 1 ? KP_TOTAL(a.K[1], a.ncurves[1]) : KP_TOTAL(a.K[0], a.ncurves[0]);
+    const float* raw_s = s == 2 ? a.raw[2] : s == 1 ? a.raw[1] : a.raw[0];
+    float r = raw_s[(size_t)b * per_img + local];
     float c = (float)exp((double)r);  // curves.py:54,106,153
     sC[i] = c;
     ws[WS_KNOTS + i] = c;
   }
+#if defined(CURL_MASK_SAMPLE)  // experiment build only (host_api.inc run_prep)
+  // Four mask dwords per thread, evenly spread over the image, asked for BEHIND the knot loads (the memory counter is in
+  // order: in front of them, every wait for a knot would also wait for these cold HBM lines) and looked at just before the
+  // second barrier -- they fly while the curves are collapsed.
+  unsigned mask_sample[4] = {1u, 1u, 1u, 1u};
+  if (a.mask_dw) {
+    const unsigned* m = a.mask_dw + (size_t)b * a.mask_dwords;
+    const unsigned step = a.mask_dwords / 1024u;  // 0 for tiny images: every sample reads dwords 0..3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mask_sample[j] = __builtin_nontemporal_load(m + min((j * 256u + threadIdx.x) * step + (unsigned)j, a.mask_dwords - 1u));
+  }
+#endif
   __syncthreads();
   // one thread per curve
   int curve0[4];
@@ -103,16 +125,31 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
   const int n_curves = curve0[3];
   const int c = threadIdx.x;
   if (c < n_curves) {
-    int s = (c >= curve0[2]) ? 2 : (c >= curve0[1]) ? 1 : 0;
-    const int local = c - curve0[s];
-    const int K = (local == a.ncurves[s] - 1) ? KP_LAST(a.K[s]) : KP_K(a.K[s]);  // torch.chunk: the last curve may be shorter
-    const float* C = sC + seg_off[s] + local * KP_K(a.K[s]);
+    // (selects over the three segments, not a.K[s]: a run-time index into a kernel argument is a global load, and its wait
+    // -- the memory counter is in order -- would also be a wait for the mask samples above)
+    const int s = (c >= curve0[2]) ? 2 : (c >= curve0[1]) ? 1 : 0;
+    const int nc_s = s == 2 ? a.ncurves[2] : s == 1 ? a.ncurves[1] : a.ncurves[0];
+    const int K_s = s == 2 ? a.K[2] : s == 1 ? a.K[1] : a.K[0];
+    const int off_s = s == 2 ? seg_off[2] : s == 1 ? seg_off[1] : seg_off[0];
+    const int local = c - (s == 2 ? curve0[2] : s == 1 ? curve0[1] : curve0[0]);
+    const int K = (local == nc_s - 1) ? KP_LAST(K_s) : KP_K(K_s);  // torch.chunk: the last curve may be shorter
+    const float* C = sC + off_s + local * KP_K(K_s);
     float ca, cb, creg;
     collapse_curve(C, K, ca, cb, creg);
     ws[WS_COEF + 2 * c] = ca;
     ws[WS_COEF + 2 * c + 1] = cb;
     sReg[c] = creg;
   }
+#if defined(CURL_MASK_SAMPLE)
+  {  // the mask samples are looked at as late as possible: their loads (cold HBM lines) have had the whole kernel to land
+    unsigned zeros = 0;
+    // (the empty asm pins the compares HERE: left alone, the compiler evaluates them right behind the loads and waits there)
+    asm volatile("" : "+v"(mask_sample[0]), "+v"(mask_sample[1]), "+v"(mask_sample[2]), "+v"(mask_sample[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zeros += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mask_sample[j] == 0u));
+    if ((threadIdx.x & 63u) == 0u) sZero[threadIdx.x >> 6] = zeros;  // wave-uniform count
+  }
+#endif
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot = 0.0f;
@@ -130,6 +167,9 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     ws[WS_MASKED + 0] = z.c0;
     ws[WS_MASKED + 1] = z.c1;
     ws[WS_MASKED + 2] = z.c2;
+#if defined(CURL_MASK_SAMPLE)
+    ws[WS_FLAG] = ((sZero[0] + sZero[1]) + (sZero[2] + sZero[3]) >= 64u) ? 1.0f : 0.0f;  // >= 1/16 of the 1 024 samples
+#endif
   }
 }
 
