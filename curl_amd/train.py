@@ -58,13 +58,13 @@ class SyntheticPairs(Dataset):
         return {"input_img": x, "output_img": y, "mask": mask, "name": f"synthetic_{i:05d}"}
 
 
-def build_net(arch, width, sync_bn):
+def build_net(arch, width, sync_bn, foreground_masks=False):
     if arch == "trispace":  # main.py:221
         net = model.TriSpaceRegNet(polynomial_order=4, spatial=True, use_sync_bn=sync_bn,
                                    backbone=model.CurveEncoder(num_outputs=1, num_features=1024, width=width,
                                                                variant="efficientnetv2_rw_t"))  # model.py:456
     else:
-        net = model.GCURLNet(backbone=model.CurveEncoder(160, width=width))
+        net = model.GCURLNet(backbone=model.CurveEncoder(160, width=width), foreground_masks=foreground_masks)
         if sync_bn:
             net = nn.SyncBatchNorm.convert_sync_batchnorm(net)
     return net
@@ -97,6 +97,9 @@ def main(argv=None):
     ap.add_argument("--width", type=float, default=1.0, help="encoder width multiplier")
     ap.add_argument("--log_dirpath", type=str, default=None, help="where checkpoints go (rank 0); none = no files")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--foreground_masks", action="store_true",
+                    help="--arch curl: the masks have sizeable empty regions (data.py:186-190) -- masked-out wavefronts skip "
+                         "their pixel loads (CURL_F_MASK_FIRST; same results)")
     ap.add_argument("--save_images", action="store_true", help="dump validation outputs under --log_dirpath (evaluate.py:49-66)")
     ap.add_argument("--amp", choices=("off", "bf16"), default="off",
                     help="bf16: torch.autocast around the encoder (stock PyTorch-ROCm); the per-pixel HIP kernels and "
@@ -126,7 +129,7 @@ def main(argv=None):
         dd = data.filter_data_dict(data.get_data_dict(root), data.get_data_ids(os.path.join(root, "images_inference.txt")))
         loader = DataLoader(data.Dataset(dd, normaliser=1, is_train=False, crop_h=args.crop, crop_w=args.crop),
                             batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
-        net = build_net(args.arch, args.width, sync_bn=False)
+        net = build_net(args.arch, args.width, sync_bn=False, foreground_masks=args.foreground_masks)
         ckpt = torch.load(args.checkpoint_filepath, map_location="cpu")
         net.load_state_dict(convert_state_dict(ckpt["model_state_dict"]))  # DP/DDP "module." prefixes removed
         net = net.to(device).eval()
@@ -157,7 +160,7 @@ def main(argv=None):
     valid_loader = DataLoader(valid_set, batch_size=args.batch_size, shuffle=False, pin_memory=True,
                               num_workers=args.num_workers, sampler=valid_sampler)
 
-    net = build_net(args.arch, args.width, sync_bn=ddp and args.backend == "nccl").to(device)
+    net = build_net(args.arch, args.width, sync_bn=ddp and args.backend == "nccl", foreground_masks=args.foreground_masks).to(device)
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
     autocast = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.amp == "bf16" else contextlib.nullcontext
