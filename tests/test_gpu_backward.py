@@ -497,6 +497,9 @@ def test_foreground_masks_skip_masked_out_wavefronts(ops, dev):
     assert torch.equal(ops.hsv_stage(d[0], d[1], d[4])[0], ops.hsv_stage(d[0], d[1], d[4], flags=F)[0])
     ref, _ = O.curl_layer(img, mask.float(), L, R, Hk)
     assert float((out1.cpu() - ref).abs().max()) <= 1e-5
+    slab = torch.zeros_like(out0)   # the row-slab entry (split-pixels layout): rows 4..20 in place, mask-first
+    ops.curl_layer_forward_rows(*d[:5], (4, 20), slab, flags=F)
+    assert torch.equal(slab[:, :, 4:20], out0[:, :, 4:20]) and not slab[:, :, :4].any() and not slab[:, :, 20:].any()
     a = ops.curl_layer_backward(*d[:5], d[5], d[6])
     b = ops.curl_layer_backward(*d[:5], d[5], d[6], flags=F)
     for x, y in zip(a, b):
