@@ -1303,3 +1303,33 @@ def test_layer_forward_and_backward_replay_from_a_hip_graph(ops, dev):
         egi, egL, egR, egH = ops.curl_layer_backward(img, mask, L, R, Hk, gout, None)
         assert torch.equal(o, eo) and torch.equal(r, er)
         assert torch.equal(gi, egi) and torch.equal(gL, egL) and torch.equal(gR, egR) and torch.equal(gH, egH)
+
+
+def test_capped_and_mask_first_launches_replay_from_a_hip_graph(ops, dev):
+    """A large launch carries launch parameters of its own -- the unused-LDS reservation that holds the resident workgroups
+    down and the mask-first kernel variant -- and they are part of the captured kernel node: replay on
+    new data equals the eager calls."""
+    g = torch.Generator().manual_seed(22)
+    B, H, W = 6, 1000, 1500   # 8 790 tiles: above the threshold where the caps apply
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.2).to(dev)
+    mask[:, :, 300:600] = False
+    R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 64))
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ops.adjust_rgb(img, R)
+            ops.hsv_stage(img, mask, Hk, flags=ops.F_MASK_FIRST)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        a, ra = ops.adjust_rgb(img, R)
+        h, rh = ops.hsv_stage(img, mask, Hk, flags=ops.F_MASK_FIRST)
+    img.copy_(torch.rand(B, 3, H, W, generator=g))
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    ea, era = ops.adjust_rgb(img, R)
+    eh, erh = ops.hsv_stage(img, mask, Hk)
+    assert torch.equal(a, ea) and torch.equal(ra, era) and torch.equal(h, eh) and torch.equal(rh, erh)
+    assert not h[:, :, 300:600].any()
