@@ -65,7 +65,7 @@ VARIANTS = {
     "aux_res5": ["-DCURL_RES_PSNR=5", "-DCURL_RES_EGRESS=5", "-DCURL_RES_INGRESS=5", "-DCURL_RES_LOSS=5", "-DCURL_RES_LOSS_BWD=5"],
     "grid_image_major": ["-DCURL_GRID_IMAGE_MAJOR"],  # stream kernels: grid = (images, tiles per image): consecutive workgroups walk different images
     "mask_sample": ["-DCURL_MASK_SAMPLE"],  # the knot-prep kernel samples the mask and the main kernel asks the workspace whether to test its mask first (exp33: +0.6 ... +1.6 % on all-ones masks)
-    "aux_res0": ["-DCURL_RES_EGRESS=0", "-DCURL_RES_INGRESS=0"],  # the byte edges uncapped (before exp27g)
+    "aux_res0": ["-DCURL_RES_EGRESS=0", "-DCURL_RES_INGRESS=0", "-DCURL_RES_PSNR=0"],  # the byte edges uncapped (before exp27g)
     "pow24_direct": ["-DCURL_POW24_DIRECT"],  # fused stages: u^2.4 as 2^(2.4 log2 u) (default: u*u * 2^(0.4 log2 u)); -1 % and one test pixel over 1e-5
     "poly1": ["-DCURL_PRIO_POLY=1"],
     "poly1_t2": ["-DCURL_PRIO_POLY=1", "-DCURL_PRIO_TRANS=2"],
