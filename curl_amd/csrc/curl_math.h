@@ -84,8 +84,7 @@ CURL_HD float div_small(float n, float d, float rd) {
 // (x * 255).astype('uint8') / to_pil_image's mul(255).byte(): truncation; out-of-range saturates
 CURL_HD unsigned unit_to_u8(float x) {
   float v = x * 255.0f;
-  v = v < 0.0f ? 0.0f : v;   // also maps NaN to 0
-  v = v > 255.0f ? 255.0f : v;
+  v = fminf(fmaxf(v, 0.0f), 255.0f);  // fmaxf(NaN, 0) = 0: NaN becomes byte 0 on the device and in the host twin alike
   return (unsigned)(int)v;
 }
 

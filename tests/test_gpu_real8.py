@@ -1,0 +1,226 @@
+"""GPU parity on REAL 8-bit content, at scale.
+
+Every production input of the reference is uint8 (data.py:133-158, infer.py:35-40): k/255 values, spatially coherent,
+with exact channel ties (colors.py:221-224 ADDS the hue terms on ties), exact zeros (colors.py:205 lifts them to 1e-9),
+saturated 255s and whole regions under the sRGB threshold 0.04045 (colors.py:37-38).  Uniformly random floats have none.
+
+  * tests/golden/real8.npz (tests/golden/make_golden_real8.py, the reference's primitives run on its own example
+    photographs): BASELINE configs[0]'s 256x256 crop IN FULL and two whole 512x341 frames, through the float32 entry
+    points and through the fused uint8 one, **strict 1e-5** (north_star) -- the reference's own float32-vs-float64 noise
+    on these frames is 4.0e-6 (crop, sat) and 9.3e-6 (dark).
+  * one 1500x1000 frame of coherent k/255 content (tools/synth8.py) against the oracle, with the size of the exception
+    set printed.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, max_err
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from curl_amd import ops as _ops
+    from curl_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return _ops
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _ref_bytes(out_f32):
+    """evaluate.py:64-66: (x * 255).astype('uint8') on the float32 CHW image, then CHW -> HWC."""
+    return np.ascontiguousarray((out_f32 * np.float32(255)).astype("uint8").transpose(0, 2, 3, 1))
+
+
+def _near_byte_boundary(out_f32, tol=1e-5):
+    """Pixels (HWC bool) where some channel of the reference's float result is within `tol` of a k/255 boundary: there a
+    float difference inside the parity bar may legitimately move the truncated byte by one."""
+    v = out_f32.astype(np.float64) * 255.0
+    return np.ascontiguousarray((np.abs(v - np.round(v)) <= tol * 255.0).transpose(0, 2, 3, 1))
+
+
+def _knots(g, tag, dev):
+    return tuple(T(g[f"{tag}_{k}"], dev) for k in "LRH")
+
+
+# (frame, max pixels allowed over the strict 1e-5, why)
+STRICT = [("crop", 0), ("sat", 0), ("dark", 8)]
+
+
+@pytest.mark.parametrize("name,n_over_allowed", STRICT)
+def test_real_photographs_layer_f32_and_u8_paths(ops, dev, golden, name, n_over_allowed):
+    """The layer on the reference's own photographs, knots of config1.npz, against the reference-generated output:
+    `crop` (BASELINE configs[0]: the 256x256 frame in full) and `sat`: EVERY value within the strict 1e-5.
+    `dark` (15.6 % of its pixels below the sRGB threshold, 9 % exact zeros): the reference's own float32 result is
+    9.3e-6 from its float64 evaluation there; a handful of pixels with an input sensitivity S of 30-100 (out-of-gamut
+    Lab->RGB met unclamped by the R curve) may pass 1e-5 -- at most 8 of 174 592, each within max(1e-5, 2e-6 * S)."""
+    import curl_oracle as O
+    g = golden("real8")
+    L, R, Hk = _knots(g, "A", dev)
+    u8 = T(g[name + "_u8"], dev)[None]                      # [1,H,W,3] uint8: PIL's layout
+    ref = g[name + "_A_out"]
+    x = ops.u8hwc_to_f32chw(u8)                             # to_tensor's byte / 255, on the device
+    assert np.array_equal(N(x), O.u8hwc_to_f32chw(g[name + "_u8"])[None].numpy())
+    H, W = x.shape[2:]
+    outs = {}
+    for label, m in (("none", None), ("bool", torch.ones(1, 1, H, W, dtype=torch.bool, device=dev)),
+                     ("f32", torch.ones(1, 1, H, W, device=dev))):
+        out, reg = ops.curl_layer_forward(x, m, L, R, Hk)
+        outs[label] = out
+        d = np.abs(N(out).astype(np.float64) - ref).max(1)[0]
+        n_over = int((d > 1e-5).sum())
+        print(f"real8 {name} mask={label}: max_err {d.max():.3e}  pixels > 1e-5: {n_over} of {d.size}")
+        assert n_over <= n_over_allowed, (name, label, n_over, float(d.max()))
+        if n_over:
+            xc = x.cpu()
+            ones = torch.ones(1, 1, H, W)
+            S = O.input_sensitivity(xc, ones, *(t.cpu() for t in (L, R, Hk)))[0].numpy()
+            assert (d <= np.maximum(1e-5, 2e-6 * S)).all(), float((d / np.maximum(1e-5, 2e-6 * S)).max())
+            assert float(S[d > 1e-5].min()) > 5.0
+        np.testing.assert_allclose(N(reg), g[name + "_A_reg"], rtol=2e-6)
+    assert torch.equal(outs["none"], outs["bool"])
+    # the fused byte path (curl_layer_fwd_u8hwc: bytes in, bytes out, one launch) against evaluate.py:64's truncation of
+    # the reference's float result: equal except where that result sits within 1e-5 of a byte boundary
+    got, reg = ops.curl_layer_forward_u8hwc(u8, None, L, R, Hk)
+    want = _ref_bytes(ref)
+    diff = N(got) != want
+    off = np.abs(N(got).astype(int) - want.astype(int))
+    near = _near_byte_boundary(ref, 1e-5 if n_over_allowed == 0 else 1e-4)
+    print(f"real8 {name} u8 path: {int(diff.any(-1).sum())} pixels differ, all at byte boundaries: {bool((~diff | near).all())}")
+    assert off.max() <= 1 and (~diff | near).all()
+    assert int(diff.any(-1).sum()) <= 2e-3 * diff.shape[1] * diff.shape[2]
+    # ... and bit for bit the three-step route on the device (ingest -> layer -> truncating egress)
+    assert torch.equal(got, ops.f32chw_to_u8hwc(outs["none"]))
+
+
+def test_config0_frame_unsaturated_knots_bool_disk_mask(ops, dev, golden):
+    """The same 256x256 frame with curves that halve their channel (raw ~ N(-0.7, 0.1)): model.py:170's
+    clamp(img + residual, 0, 1) never saturates, so every unmasked output value carries the chain's arithmetic; bool disk
+    mask (data.py:190's dtype).  Strict 1e-5, masked-out pixels exactly 0."""
+    g = golden("real8")
+    L, R, Hk = _knots(g, "B", dev)
+    x = ops.u8hwc_to_f32chw(T(g["crop_u8"], dev)[None])
+    disk = T(g["crop_disk"], dev)
+    ref = g["crop_B_disk_out"]
+    assert float((ref == 1).mean()) == 0.0
+    for m in (disk, disk.float()):
+        out, reg = ops.curl_layer_forward(x, m, L, R, Hk)
+        assert max_err(N(out), ref) <= 1e-5
+        assert (N(out)[:, :, ~g["crop_disk"][0, 0]] == 0).all()
+        np.testing.assert_allclose(N(reg), g["crop_B_disk_reg"], rtol=2e-6)
+    got, _ = ops.curl_layer_forward_u8hwc(T(g["crop_u8"], dev)[None], disk, L, R, Hk)
+    want = _ref_bytes(ref)
+    diff = N(got) != want
+    assert (~diff | _near_byte_boundary(ref)).all() and np.abs(N(got).astype(int) - want.astype(int)).max() <= 1
+
+
+def test_config0_frame_per_colour_space_stages(ops, dev, golden):
+    """north_star's "one fused kernel per colour space" on the real frame (rows 64..192 of the crop): the Lab stage
+    (model.py:151-157, the kernel the 70 % target is stated on) and the HSV stage (model.py:163-169) -- the latter meets
+    the 8-bit image's exact channel ties directly (18 % of these pixels).  Strict: 1e-5 / 3e-6."""
+    g = golden("real8")
+    L, R, Hk = _knots(g, "A", dev)
+    r0, r1 = (int(v) for v in g["stage_rows"])
+    x = ops.u8hwc_to_f32chw(T(g["crop_u8"], dev)[None])[:, :, r0:r1].contiguous()
+    ties = (g["crop_u8"][r0:r1, :, 0] == g["crop_u8"][r0:r1, :, 1]) | (g["crop_u8"][r0:r1, :, 1] == g["crop_u8"][r0:r1, :, 2]) | \
+           (g["crop_u8"][r0:r1, :, 0] == g["crop_u8"][r0:r1, :, 2])
+    assert ties.mean() > 0.1
+    for m in (None, torch.ones(1, 1, r1 - r0, x.shape[3], dtype=torch.bool, device=dev)):
+        out, reg = ops.lab_stage(x, m, L)
+        assert max_err(N(out), g["crop_A_lab_stage"]) <= 1e-5
+        np.testing.assert_allclose(N(reg), g["crop_A_lab_stage_reg"], rtol=2e-6)
+        out, reg = ops.hsv_stage(x, m, Hk)
+        assert max_err(N(out), g["crop_A_hsv_stage"]) <= 3e-6
+        np.testing.assert_allclose(N(reg), g["crop_A_hsv_stage_reg"], rtol=2e-6)
+
+
+def test_fullsize_coherent_8bit_frame_vs_oracle(ops, dev):
+    """One 1500x1000 frame of spatially coherent k/255 content (tools/synth8.py: gradients, grey ramps, flat dark patches,
+    tie palettes, saturated highlights -- exact ties and exact zeros over whole wavefronts) against the oracle, bench
+    knots (sigma 0.1).  Strict 1e-5 on every pixel where the chain is well conditioned; the exception set (pixels over
+    1e-5) is printed, must be tiny, ill-conditioned (S > 5) and inside max(1e-5, 2e-6 * S)."""
+    import curl_oracle as O
+    import synth8
+    H, W = 1000, 1500
+    u8 = synth8.coherent_8bit_frames(1, H, W, seed=1)
+    stats = synth8.describe(u8)
+    assert stats["ties"] > 0.3 and stats["zero_channel"] > 0.1 and stats["saturated_channel"] > 0.1
+    g = torch.Generator().manual_seed(123)
+    L, R, Hk = (torch.randn(1, n, generator=g) * 0.1 for n in (48, 48, 64))
+    x = O.u8hwc_to_f32chw(u8[0])[None]
+    ones = torch.ones(1, 1, H, W)
+    ref, ref_reg = O.curl_layer(x, ones, L, R, Hk)
+    r64, _ = O.curl_layer(x.double(), ones.double(), L.double(), R.double(), Hk.double())
+    u8d = T(u8, dev)
+    xd = ops.u8hwc_to_f32chw(u8d)
+    assert torch.equal(xd.cpu(), x)
+    out, reg = ops.curl_layer_forward(xd, None, L.to(dev), R.to(dev), Hk.to(dev))
+    d = (out.cpu().double() - ref.double()).abs().amax(1)[0]
+    ours = (out.cpu().double() - r64).abs().amax(1)[0]
+    noise = (ref.double() - r64).abs().amax(1)[0]
+    over = d > 1e-5
+    print(f"coherent 8-bit 1500x1000 ({stats}): max_err {float(d.max()):.3e} (vs float64 {float(ours.max()):.3e}; the reference's own "
+          f"float32 noise {float(noise.max()):.3e}); exception set: {int(over.sum())} of {d.numel()} pixels over 1e-5")
+    if int(over.sum()):
+        S = O.input_sensitivity(x, ones, L, R, Hk, r64=r64)[0]
+        bound = torch.clamp(2e-6 * S, min=1e-5)
+        assert int((d > bound).sum()) == 0 and float(S[over].min()) > 5.0
+    assert int(over.sum()) <= 1e-5 * d.numel()
+    np.testing.assert_allclose(N(reg), ref_reg.numpy(), rtol=2e-6)
+    # bytes: the fused uint8 path against the truncation of the oracle's float result
+    got, _ = ops.curl_layer_forward_u8hwc(u8d, None, L.to(dev), R.to(dev), Hk.to(dev))
+    want = _ref_bytes(ref.numpy())
+    diff = N(got) != want
+    print(f"coherent 8-bit bytes: {int(diff.any(-1).sum())} of {H * W} pixels differ (byte boundaries)")
+    assert np.abs(N(got).astype(int) - want.astype(int)).max() <= 1 and (~diff | _near_byte_boundary(ref.numpy())).all()
+    assert torch.equal(got, ops.f32chw_to_u8hwc(out))
+    # wavefronts of exact zeros / exact ties: black stays what the reference makes of it, greys stay grey-consistent
+    black = (u8[0] == 0).all(-1)
+    assert black.sum() > 1000
+    assert np.array_equal(N(out)[0][:, black], ref.numpy()[0][:, black]) or max_err(N(out)[0][:, black], ref.numpy()[0][:, black]) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 48), (2, 7, 9)])
+def test_u8_path_float_mask_outside_unit_range_saturates(ops, dev, shape):
+    """CURL_MASK_F32 is 'multiplied as is', so a float mask of 2.0, -1.0 or NaN takes the layer's result
+    out of [0, 1].  The fused byte egress must saturate there (255 / 0 / 0) like curl_f32chw_to_u8hwc does, not wrap a byte
+    into its neighbours: equal, byte for byte, to the float32 layer followed by the saturating egress (float4 and scalar
+    paths)."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+    m = torch.rand(B, 1, H, W, generator=g)
+    m.view(-1)[0::7] = 2.0
+    m.view(-1)[1::7] = -1.0
+    m.view(-1)[2::7] = float("nan")
+    m.view(-1)[3::7] = 1.0
+    m = m.to(dev)
+    got, _ = ops.curl_layer_forward_u8hwc(u8, m, L, R, Hk)
+    out, _ = ops.curl_layer_forward(ops.u8hwc_to_f32chw(u8), m, L, R, Hk)
+    want = ops.f32chw_to_u8hwc(out)
+    assert torch.equal(got, want)
+    o = N(out).transpose(0, 2, 3, 1)
+    b = N(got)
+    assert (b[o >= 1.0] == 255).all() and (b[o <= 0.0] == 0).all() and (b[np.isnan(o)] == 0).all()
+    assert (o >= 1.0).sum() > 0 and np.isnan(o).sum() > 0 and (o < 0).sum() > 0
