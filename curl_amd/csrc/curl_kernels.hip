@@ -23,9 +23,7 @@
 
 using namespace curlm;
 
-#ifndef CURL_TRISPACE_WAVES
-#define CURL_TRISPACE_WAVES 4  // register budget of the polynomial kernel: 128 VGPRs (it needs ~106)
-#endif
+constexpr int kTriSpaceWaves = 4;  // register budget of the polynomial kernel: 128 VGPRs (it needs ~106)
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -51,7 +49,6 @@ static int hip_fail(hipError_t e, const char* where) {
 #define WS_COEF 0
 #define WS_REG 20
 #define WS_MASKED 24
-#define WS_FLAG 28  // 1.0f: the image's bool / uint8 mask has sizeable empty regions (knots_prep_kernel's sample)
 #define WS_KNOTS 32
 #define MAX_CURVES 10
 
@@ -72,10 +69,6 @@ struct PrepArgs {
   float* ws;
   float* reg_out;  // nullable, [B], assigned
   unsigned stride;
-  // bool / uint8 mask of the images as dwords (4 pixels each), or NULL: 1 024 of them per image are sampled while the knots
-  // are on their way, and ws[WS_FLAG] says whether >= 1/16 of them were entirely zero
-  const unsigned* mask_dw;
-  unsigned mask_dwords;  // per image
 };
 
 // One workgroup per image.  exp in float64 (rounded once to float32: the best estimate of torch.exp's
@@ -83,9 +76,6 @@ struct PrepArgs {
 __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
   __shared__ float sC[MAX_CURVES * CURL_MAX_KNOTS];
   __shared__ float sReg[MAX_CURVES];
-#if defined(CURL_MASK_SAMPLE)
-  __shared__ unsigned sZero[4];
-#endif
   const unsigned b = blockIdx.x;
   float* ws = a.ws + (size_t)b * a.stride;
 
@@ -104,18 +94,6 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     sC[i] = c;
     ws[WS_KNOTS + i] = c;
   }
-#if defined(CURL_MASK_SAMPLE)  // experiment build only (host_api.inc run_prep)
-  // Four mask dwords per thread, evenly spread over the image, asked for BEHIND the knot loads (the memory counter is in
-  // order: in front of them, every wait for a knot would also wait for these cold HBM lines) and looked at just before the
-  // second barrier -- they fly while the curves are collapsed.
-  unsigned mask_sample[4] = {1u, 1u, 1u, 1u};
-  if (a.mask_dw) {
-    const unsigned* m = a.mask_dw + (size_t)b * a.mask_dwords;
-    const unsigned step = a.mask_dwords / 1024u;  // 0 for tiny images: every sample reads dwords 0..3
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mask_sample[j] = __builtin_nontemporal_load(m + min((j * 256u + threadIdx.x) * step + (unsigned)j, a.mask_dwords - 1u));
-  }
-#endif
   __syncthreads();
   // one thread per curve
   int curve0[4];
@@ -125,8 +103,7 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
   const int n_curves = curve0[3];
   const int c = threadIdx.x;
   if (c < n_curves) {
-    // (selects over the three segments, not a.K[s]: a run-time index into a kernel argument is a global load, and its wait
-    // -- the memory counter is in order -- would also be a wait for the mask samples above)
+    // (selects over the three segments, not a.K[s]: a run-time index into a kernel argument is a global load)
     const int s = (c >= curve0[2]) ? 2 : (c >= curve0[1]) ? 1 : 0;
     const int nc_s = s == 2 ? a.ncurves[2] : s == 1 ? a.ncurves[1] : a.ncurves[0];
     const int K_s = s == 2 ? a.K[2] : s == 1 ? a.K[1] : a.K[0];
@@ -140,16 +117,6 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     ws[WS_COEF + 2 * c + 1] = cb;
     sReg[c] = creg;
   }
-#if defined(CURL_MASK_SAMPLE)
-  {  // the mask samples are looked at as late as possible: their loads (cold HBM lines) have had the whole kernel to land
-    unsigned zeros = 0;
-    // (the empty asm pins the compares HERE: left alone, the compiler evaluates them right behind the loads and waits there)
-    asm volatile("" : "+v"(mask_sample[0]), "+v"(mask_sample[1]), "+v"(mask_sample[2]), "+v"(mask_sample[3]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) zeros += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mask_sample[j] == 0u));
-    if ((threadIdx.x & 63u) == 0u) sZero[threadIdx.x >> 6] = zeros;  // wave-uniform count
-  }
-#endif
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot = 0.0f;
@@ -167,9 +134,6 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     ws[WS_MASKED + 0] = z.c0;
     ws[WS_MASKED + 1] = z.c1;
     ws[WS_MASKED + 2] = z.c2;
-#if defined(CURL_MASK_SAMPLE)
-    ws[WS_FLAG] = ((sZero[0] + sZero[1]) + (sZero[2] + sZero[3]) >= 64u) ? 1.0f : 0.0f;  // >= 1/16 of the 1 024 samples
-#endif
   }
 }
 

@@ -172,7 +172,7 @@ struct Px {
 // ~5.8 ns per SIMD, the same instruction in a run of its own kind ~4.3 ns (alone 3.5).  The converters are
 // therefore written over the N pixels a lane owns, as phases: every phase of transcendentals is a run of
 // 3N (or N) back-to-back v_log / v_exp / v_rcp, fenced so the scheduler cannot interleave it again.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CURL_NO_FENCE)  // CURL_NO_FENCE: experiment build (tools/variants.py)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define CURL_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define CURL_FENCE() ((void)0)
@@ -190,29 +190,12 @@ struct PxN {
 // the layer kernel's instructions, tools/ubench/issue_pair.hip reproduces it).  Raising the priority of a wave while
 // it runs its packed / transcendental runs makes those runs drain back to back, which leaves the other waves of the
 // SIMD in plain code at the same time -- where they pair.
-//   CURL_PRIO_TRANS / CURL_PRIO_PK / CURL_PRIO_FAST : s_setprio levels of the three kinds of code (0..3).
 // Measured on the fused layer (profiles/r02/issue_priority_ab.log, bs32 x 1500x1000): all at one priority 2.5 % of
 // the instructions pair and the kernel takes 254 us; transcendental (and packed) runs at priority 1: 26 % pair,
 // 217 us; the same with the element-wise helpers as scalar instead of packed code (they can pair, packed ones
-// never do): 40 % pair, 213 us -- the default.  Arithmetic-only time 237 -> 183 us.
-#if !defined(CURL_PRIO_FAST)
-#define CURL_PRIO_FAST 0
-#endif
-#if !defined(CURL_PRIO_TRANS) && !defined(CURL_EXP_PRIO)
-#define CURL_PRIO_TRANS 1
-#endif
-#if defined(CURL_EXP_PRIO)  // first experiment (plain code at raised priority): kept for the A/B record
-#undef CURL_PRIO_FAST
-#define CURL_PRIO_FAST CURL_EXP_PRIO
-#define CURL_PRIO_PK 0
-#define CURL_PRIO_TRANS 0
-#endif
-#if !defined(CURL_PRIO_PK)
-#define CURL_PRIO_PK CURL_PRIO_FAST
-#endif
-#if !defined(CURL_PRIO_TRANS)
-#define CURL_PRIO_TRANS CURL_PRIO_FAST
-#endif
+// never do): 40 % pair, 213 us -- what is built here: plain code at priority 0, transcendental runs at 1.  (The packed
+// helpers, other priority levels and the polynomial model's Horner code at a raised priority were measured and are not
+// built: tools/experiments/patches/.)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CURL_SETPRIO(n)                  \
   do {                                   \
@@ -223,49 +206,13 @@ struct PxN {
 #else
 #define CURL_SETPRIO(n) ((void)0)
 #endif
-#if CURL_PRIO_PK != CURL_PRIO_FAST
-#define CURL_SLOW_BEGIN() CURL_SETPRIO(CURL_PRIO_PK)
-#define CURL_SLOW_END() CURL_SETPRIO(CURL_PRIO_FAST)
-#else
-#define CURL_SLOW_BEGIN() ((void)0)
-#define CURL_SLOW_END() ((void)0)
-#endif
-#if CURL_PRIO_TRANS != CURL_PRIO_FAST || CURL_PRIO_PK != CURL_PRIO_FAST
-#define CURL_TRANS_BEGIN() CURL_SETPRIO(CURL_PRIO_TRANS)
-#define CURL_TRANS_END() CURL_SETPRIO(CURL_PRIO_FAST)
-#else
-#define CURL_TRANS_BEGIN() ((void)0)
-#define CURL_TRANS_END() ((void)0)
-#endif
-// the polynomial model's packed Horner code (curl_math_poly.h): CURL_PRIO_POLY, default = plain code's level
-#if !defined(CURL_PRIO_POLY)
-#define CURL_PRIO_POLY CURL_PRIO_FAST
-#endif
-#if CURL_PRIO_POLY != CURL_PRIO_FAST
-#define CURL_POLY_BEGIN() CURL_SETPRIO(CURL_PRIO_POLY)
-#define CURL_POLY_END() CURL_SETPRIO(CURL_PRIO_FAST)
-#else
-#define CURL_POLY_BEGIN() ((void)0)
-#define CURL_POLY_END() ((void)0)
-#endif
-//   CURL_EXP_VCONST : experiment build, constants and curve coefficients of the scalar FMAs in VGPRs instead of SGPRs.
-CURL_HD float vconst(float k) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CURL_EXP_VCONST)
-  asm("" : "+v"(k));  // an opaque VGPR value: instructions that use it carry no SGPR operand
-#endif
-  return k;
-}
+#define CURL_TRANS_BEGIN() CURL_SETPRIO(1)
+#define CURL_TRANS_END() CURL_SETPRIO(0)
 
-// Packed FP32: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes-worth of work per instruction at
-// 1.75 ns per SIMD against 2 x 1.07 ns for the scalar forms (tools/ubench/sustained.hip).  hipcc's SLP
-// vectoriser does not form them on its own here, so the element-wise loops over a lane's pixels go through
-// these helpers: arrays are PLANE-MAJOR (index c*N + i), so elements 2k, 2k+1 are two pixels of one channel
-// and sit in adjacent registers straight from the float4 loads.
-// CURL_USE_PK (experiment build, the round-1 code): packed v_pk_* helpers.  Default: scalar loops -- two scalar
-// instructions of different waves share a quad-cycle, which a packed instruction (alone in its quad) only equals.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CURL_USE_PK)
-#define CURL_PK 1
-#endif
+// Two-float vectors for the polynomial model's packed Horner chains (curl_math_poly.h: an FMA-only stream pairs only 72 %
+// of its three-VGPR-operand instructions, so v_pk_fma_f32 wins there).  The converters' element-wise loops below are SCALAR:
+// two scalar instructions of different waves share a quad-cycle, which a packed instruction (alone in its quad) only equals
+// (measured: layer 217 us packed, 213 us scalar).
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float curl_f2 __attribute__((ext_vector_type(2)));
 CURL_HD curl_f2 splat2(float k) {
@@ -289,74 +236,35 @@ CURL_HD void st2(float* a, int i, curl_f2 v) {
 // y = a*k + c, element-wise over M values (k, c scalars)
 template <int M>
 CURL_HD void fma_run(float (&y)[M], const float (&a)[M], float k, float c) {
-#if defined(CURL_PK)
-  CURL_SLOW_BEGIN();
-#pragma unroll
-  for (int i = 0; i + 1 < M; i += 2) st2(y, i, __builtin_elementwise_fma(ld2(a, i), splat2(k), splat2(c)));
-  if (M & 1) y[M - 1] = fmaf(a[M - 1], k, c);
-  CURL_SLOW_END();
-#else
   for (int i = 0; i < M; ++i) y[i] = fmaf(a[i], k, c);
-#endif
 }
 // y = a*b element-wise
 template <int M>
 CURL_HD void mul_run(float (&y)[M], const float (&a)[M], const float (&b)[M]) {
-#if defined(CURL_PK)
-  CURL_SLOW_BEGIN();
-#pragma unroll
-  for (int i = 0; i + 1 < M; i += 2) st2(y, i, ld2(a, i) * ld2(b, i));
-  if (M & 1) y[M - 1] = a[M - 1] * b[M - 1];
-  CURL_SLOW_END();
-#else
   for (int i = 0; i < M; ++i) y[i] = a[i] * b[i];
-#endif
 }
 // y = a*k
 template <int M>
 CURL_HD void scale_run(float (&y)[M], const float (&a)[M], float k) {
-#if defined(CURL_PK)
-  CURL_SLOW_BEGIN();
-#pragma unroll
-  for (int i = 0; i + 1 < M; i += 2) st2(y, i, ld2(a, i) * splat2(k));
-  if (M & 1) y[M - 1] = a[M - 1] * k;
-  CURL_SLOW_END();
-#else
   for (int i = 0; i < M; ++i) y[i] = a[i] * k;
-#endif
 }
 // y = k - a   (the sign of thr - x drives every threshold select)
 template <int M>
 CURL_HD void rsub_run(float (&y)[M], float k, const float (&a)[M]) {
-#if defined(CURL_PK)
-  CURL_SLOW_BEGIN();
-#pragma unroll
-  for (int i = 0; i + 1 < M; i += 2) st2(y, i, splat2(k) - ld2(a, i));
-  if (M & 1) y[M - 1] = k - a[M - 1];
-  CURL_SLOW_END();
-#else
   for (int i = 0; i < M; ++i) y[i] = k - a[i];
-#endif
 }
 // The threshold selects of the converters (x <= thr ? a : b, twelve per pixel) on the device: v_cmp_le_f32_e64 into an
 // SGPR pair + v_cndmask_b32_e64 (the VOP3 form with its mask in SGPRs issues in 4 cycles; it is the VOP2 form with the
 // mask in VCC, what hipcc emits for `?:`, that takes 23).  Two instructions with two VGPR reads each instead of
 // sub / ashr / bitop3: 750 instead of 798 instructions per wave and ~0.7 nJ less per select (tools/ubench/energy.hip),
 // which is what counts under the board's power cap: layer 239.7 -> 236.8 us, Lab stage 199.1 -> 197.3 us on one box
-// (profiles/r02/select_cndmask_ab.log).  -DCURL_SELECT_BITWISE rebuilds the sign-bit form (which the host twin uses:
-// same values, also for x == thr; a NaN takes the second branch here, as the reference's `x <= thr` mask does).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CURL_SELECT_BITWISE)
-#define CURL_SELECT_CNDMASK 1
-#endif
-#if defined(CURL_SELECT_CNDMASK)
+// (profiles/r02/select_cndmask_ab.log).  The host twin uses the sign-bit form: same values, also for x == thr (a NaN
+// takes the second branch here, as the reference's `x <= thr` mask does).
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float select_le_hw(float x, float thr, float a, float b) {
   unsigned long long m;
   float r;
-#if defined(CURL_SELECT_VTHR)  // experiment build: the threshold in a VGPR, so that the compare reads no SGPR
-  asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(thr));
-#else
   asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(thr));
-#endif
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
   return r;
 }
@@ -373,7 +281,7 @@ __device__ __forceinline__ float zero_if_less_hw(float c, float mx, float val) {
 // out = (x <= thr) ? a : b  element-wise (thr scalar)
 template <int M>
 CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, const float (&a)[M], const float (&b)[M]) {
-#if defined(CURL_SELECT_CNDMASK)
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
   for (int i = 0; i < M; ++i) out[i] = select_le_hw(x[i], thr, a[i], b[i]);
   return;
@@ -390,16 +298,12 @@ CURL_HD void select_le_run(float (&out)[M], const float (&x)[M], float thr, cons
 // instructions.  The four threshold selects of the Lab converters pick their linear branch for dark values only (sRGB
 // x <= 0.04045, XYZ t <= 0.008856, f <= 6/29, linear v <= 0.0031308): a wave of a photograph's mid-tones takes none of them;
 // of uniformly random pixels (the benchmark) ~30 % of the waves skip the two XYZ-side ones.  The kernel runs at the board's
-// power cap, where instructions are joules.  CURL_NO_LAZY_SELECT rebuilds the eager form.
-#if defined(CURL_SELECT_CNDMASK) && !defined(CURL_NO_LAZY_SELECT)
-#define CURL_LAZY_SELECT 1
+// power cap, where instructions are joules.
+#if defined(__HIP_DEVICE_COMPILE__)
 // ... and inside the branch the linear value is not computed for every lane and then selected: the multiply (or fma) itself
 // runs PREDICATED -- exec narrowed to the lanes whose compare said "linear branch" -- and overwrites the pow branch's value
 // in place there: one VALU instruction and two scalar ones per value instead of two VALU instructions (the scalar unit is
-// a pipe of its own).  s_and_saveexec / restore, so a caller's partial exec mask is respected.  CURL_NO_PRED_SELECT:
-// the v_cndmask form (A/B).
-#if !defined(CURL_NO_PRED_SELECT)
-#define CURL_PRED_SELECT 1
+// a pipe of its own).  s_and_saveexec / restore, so a caller's partial exec mask is respected.
 __device__ __forceinline__ void pred_mul(float& dst, unsigned long long m, float x, float k_uniform) {  // dst = x * k where m
   unsigned long long t;
   asm("s_and_saveexec_b64 %1, %2\n\tv_mul_f32_e32 %0, %4, %3\n\ts_mov_b64 exec, %1"
@@ -415,7 +319,6 @@ __device__ __forceinline__ void pred_fma(float& dst, unsigned long long m, float
   asm("s_and_saveexec_b64 %1, %2\n\tv_fma_f32 %0, %3, %4, %5\n\ts_mov_b64 exec, %1"
       : "+v"(dst), "=&s"(t) : "s"(m), "v"(x), "s"(k_uniform), "v"(c_vgpr) : "scc");
 }
-#endif
 // A(r, m): overwrite r[i] with the linear branch where m[i] (predicated form), or A(av): compute it for every lane.
 // BRANCH = false: no wave-uniform skip, only the predicated overwrites (the predicates are consumed one by one instead of
 // being held across a branch: for kernels at their register budget)
@@ -467,20 +370,7 @@ CURL_HD void pow_run(float (&x)[M], float e) {
 // row r of a 3x3 matrix applied to plane-major (c*N + i) data: y[i] = m0*a[i] + m1*a[N+i] + m2*a[2N+i]
 template <int N>
 CURL_HD void mat_row(float (&y)[N], const float (&a)[3 * N], float m0, float m1, float m2) {
-#if defined(CURL_PK)
-  CURL_SLOW_BEGIN();
-#pragma unroll
-  for (int i = 0; i + 1 < N; i += 2) {
-    curl_f2 acc = splat2(m0) * ld2(a, i);
-    acc = __builtin_elementwise_fma(splat2(m1), ld2(a, N + i), acc);
-    acc = __builtin_elementwise_fma(splat2(m2), ld2(a, 2 * N + i), acc);
-    st2(y, i, acc);
-  }
-  if (N & 1) y[N - 1] = fmaf(m2, a[3 * N - 1], fmaf(m1, a[2 * N - 1], m0 * a[N - 1]));
-  CURL_SLOW_END();
-#else
   for (int i = 0; i < N; ++i) y[i] = fmaf(m2, a[2 * N + i], fmaf(m1, a[N + i], m0 * a[i]));
-#endif
 }
 
 // ---------------------------------------------------------------- RGB -> Lab   colors.py:27-62
@@ -501,31 +391,20 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
   // hardware log/exp errors (1 ulp each) cost ~1e-7 relative instead of ~4e-7 (the direct form fails the
   // 1e-5 end-to-end bar on out-of-range inputs).  torch raises to float32(2.4); 2.4f - 2.0f is exact.
   fma_run(g, x, kInv1055, (float)(0.055 / 1.055));
-  // CURL_POW24_DIRECT (experiment build, tools/variants.py pow24_direct): the fused stages take 2^(2.4*log2 u) directly, two
-  // VALU instructions per value fewer: layer -1.0 %, error distributions against the oracle unchanged on in-range images
-  // -- but one out-of-range pixel of test_odd_shapes_and_tails moves from under to over the 1e-5 bar (1.11e-5), so the
-  // product keeps the split form (profiles/r03/exp26_*.log).
-#if defined(CURL_POW24_DIRECT)
-  if constexpr (LAZY != 0) {
-    pow_run(g, kGamma);
-  } else
-#endif
+  // (2^(2.4*log2 u) taken directly saves two VALU instructions per value and 1 % of the layer's time, and moves one
+  // out-of-range pixel of test_odd_shapes_and_tails over the 1e-5 bar: not built, profiles/r03/exp26_*.log.)
   {
     mul_run(u2, g, g);
     pow_run(g, kGammaFrac);
     mul_run(g, u2, g);
   }
-#if defined(CURL_LAZY_SELECT)
+#if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LAZY != 0) {
     const float (&xr)[3 * N] = x;
-#if defined(CURL_PRED_SELECT)
     select_le_lazy<LAZY == 1>(x, x, kSrgbThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
 #pragma unroll
       for (int i = 0; i < 3 * N; ++i) pred_mul(r[i], m[i], xr[i], kInv1292);
     }, g);
-#else
-    select_le_lazy<LAZY == 1>(x, x, kSrgbThr, [&](float (&av)[3 * N]) { scale_run(av, xr, kInv1292); }, g);
-#endif
   } else
 #endif
   {
@@ -546,18 +425,14 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 #pragma unroll
   for (int i = 0; i < 3 * N; ++i) f[i] = t[i];
   pow_run(f, kThird);
-#if defined(CURL_LAZY_SELECT)
+#if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LAZY != 0) {
     const float (&tr)[3 * N] = t;
-#if defined(CURL_PRED_SELECT)
     select_le_lazy<LAZY == 1>(f, t, kEps3, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
       const float c = k4_29;
 #pragma unroll
       for (int i = 0; i < 3 * N; ++i) pred_fma(r[i], m[i], tr[i], kInv3Eps2, c);
     }, f);
-#else
-    select_le_lazy<LAZY == 1>(f, t, kEps3, [&](float (&av)[3 * N]) { fma_run(av, tr, kInv3Eps2, k4_29); }, f);
-#endif
   } else
 #endif
   {
@@ -569,9 +444,9 @@ CURL_HD void rgb2lab_n(PxN<N>& p) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     float fx = f[i], fy = f[N + i], fz = f[2 * N + i];
-    p.c0[i] = fmaf(fy, vconst(1.16f), vconst(-0.16f));
-    p.c1[i] = fmaf(fx - fy, vconst((float)(500.0 / 220.0)), 0.5f);
-    p.c2[i] = fmaf(fy - fz, vconst((float)(200.0 / 220.0)), 0.5f);
+    p.c0[i] = fmaf(fy, 1.16f, -0.16f);
+    p.c1[i] = fmaf(fx - fy, (float)(500.0 / 220.0), 0.5f);
+    p.c2[i] = fmaf(fy - fz, (float)(200.0 / 220.0), 0.5f);
   }
 }
 
@@ -583,9 +458,9 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   for (int i = 0; i < N; ++i) {
     // colors.py:97-99 (L*100, (a*2-1)*110, (b*2-1)*110) and colors.py:79-81,104-106
     // (fy = (L+16)/116, fx = fy + a/500, fz = fy - b/200) with the constants folded:
-    float fy = fmaf(p.c0[i], vconst((float)(100.0 / 116.0)), vconst((float)(16.0 / 116.0)));
-    float fx = fmaf(p.c1[i], vconst((float)(220.0 / 500.0)), fy - (float)(110.0 / 500.0));
-    float fz = fmaf(p.c2[i], vconst((float)(-220.0 / 200.0)), fy + (float)(110.0 / 200.0));
+    float fy = fmaf(p.c0[i], (float)(100.0 / 116.0), (float)(16.0 / 116.0));
+    float fx = fmaf(p.c1[i], (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0));
+    float fz = fmaf(p.c2[i], (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0));
     X[i] = fx, X[N + i] = fy, X[2 * N + i] = fz;
   }
   {
@@ -593,18 +468,14 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     float cub[3 * N];
     mul_run(cub, X, X);
     mul_run(cub, cub, X);
-#if defined(CURL_LAZY_SELECT)
+#if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (LAZY != 0) {
       const float (&Xr)[3 * N] = X;
-#if defined(CURL_PRED_SELECT)
       select_le_lazy<LAZY == 1>(X, X, kEps, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
         const float c = -(k3Eps2 * k4_29);
 #pragma unroll
         for (int i = 0; i < 3 * N; ++i) pred_fma(r[i], m[i], Xr[i], k3Eps2, c);
       }, cub);
-#else
-      select_le_lazy<LAZY == 1>(X, X, kEps, [&](float (&av)[3 * N]) { fma_run(av, Xr, k3Eps2, -(k3Eps2 * k4_29)); }, cub);
-#endif
     } else
 #endif
     {
@@ -627,17 +498,13 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
   pow_run(g, kInvGamma);
   if (!CLAMP12) {
     fma_run(g, g, 1.055f, -0.055f);
-#if defined(CURL_LAZY_SELECT)
+#if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (LAZY != 0) {
       const float (&vr)[3 * N] = v;
-#if defined(CURL_PRED_SELECT)
       select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
 #pragma unroll
         for (int i = 0; i < 3 * N; ++i) pred_mul(r[i], m[i], vr[i], 12.92f);
       }, g);
-#else
-      select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&av)[3 * N]) { scale_run(av, vr, 12.92f); }, g);
-#endif
     } else
 #endif
     {
@@ -656,35 +523,26 @@ CURL_HD void lab2rgb_n(PxN<N>& p) {
     rsub_run(d, kLinThr, v);
 #pragma unroll
     for (int i = 0; i < N; ++i) g[i] = g0[i], lin[i] = l0[i];
-#if defined(CURL_LAZY_SELECT)
+#if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (LAZY != 0) {
 #pragma unroll
-      for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
+      for (int i = N; i < 3 * N; ++i) g[i] = clamp01(fmaf(g[i], 1.055f, -0.055f));
       const float (&vr)[3 * N] = v;
-#if defined(CURL_PRED_SELECT)
       select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&r)[3 * N], const unsigned long long (&m)[3 * N]) {
 #pragma unroll
         for (int i = 0; i < N; ++i) pred_mul(r[i], m[i], vr[i], 12.92f);
 #pragma unroll
         for (int i = N; i < 3 * N; ++i) pred_mul_clamp(r[i], m[i], vr[i], 12.92f);
       }, g);
-#else
-      select_le_lazy<LAZY == 1>(v, v, kLinThr, [&](float (&av)[3 * N]) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) av[i] = vr[i] * 12.92f;
-#pragma unroll
-        for (int i = N; i < 3 * N; ++i) av[i] = clamp01(vr[i] * vconst(12.92f));
-      }, g);
-#endif
     } else
 #endif
     {
 #pragma unroll
       for (int i = N; i < 3 * N; ++i) {
-        g[i] = clamp01(fmaf(g[i], vconst(1.055f), vconst(-0.055f)));
-        lin[i] = clamp01(v[i] * vconst(12.92f));
+        g[i] = clamp01(fmaf(g[i], 1.055f, -0.055f));
+        lin[i] = clamp01(v[i] * 12.92f);
       }
-#if defined(CURL_SELECT_CNDMASK)
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
       for (int i = 0; i < 3 * N; ++i) v[i] = select_le_hw(v[i], kLinThr, lin[i], g[i]);
 #else
@@ -723,11 +581,7 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // UNIT: + 1e-30 keeps the reciprocal finite when df == 0, so that s = df * df * q is an exact 0 there without a mask
     // (one fma instead of mul + and); df * mx >= 6e-8 * mx for any two distinct floats <= mx, so the addend changes q
     // only where mx < 1e-20 -- and v = mx scales everything the HSV stage contributes to the output.
-#if defined(CURL_R2_HSV)
-    rdm[i] = -nd[i] * mx[i];
-#else
     rdm[i] = UNIT ? fmaf(-nd[i], mx[i], 1e-30f) : -nd[i] * mx[i];
-#endif
   }
   CURL_FENCE();
   CURL_TRANS_BEGIN();
@@ -741,7 +595,7 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // colors.py:221-224: the three sextant terms ADD when channels tie for the maximum.
     // [c == mx] as a bit mask: c - mx is negative exactly when c is NOT the maximum (+0 when it is), so one
     // arithmetic shift gives the complement mask and one and-not applies it.
-#if defined(CURL_SELECT_CNDMASK) && !defined(CURL_HUE_BITWISE)
+#if defined(__HIP_DEVICE_COMPILE__)
     float t0 = zero_if_less_hw(r[i], mx[i], (g[i] - b[i]) * dfi);
     float t1 = zero_if_less_hw(g[i], mx[i], fmaf(b[i] - r[i], dfi, 2.0f));
     float t2 = zero_if_less_hw(b[i], mx[i], fmaf(r[i] - g[i], dfi, 4.0f));
@@ -755,14 +609,10 @@ CURL_HD void rgb2hsv_n(PxN<N>& p) {
     // colors.py:225-231: *60, negative hues + 360, /360  ==  (negative sextants + 6) / 6
     // (not fract(h/6): two channels tying for the maximum at g == b add up to h6 = 6 exactly, which must stay
     // hue 1.0, not wrap to 0 -- the hue curves of adjust_hsv are not periodic)
-    if (UNIT) h = fmaf(h, vconst((float)(1.0 / 6.0)), keep_if(neg_mask(h), 1.0f));
+    if (UNIT) h = fmaf(h, (float)(1.0 / 6.0), keep_if(neg_mask(h), 1.0f));
     else h = (h + keep_if(neg_mask(h), 6.0f)) * (float)(1.0 / 6.0);
     float s = nd[i] * (rdm[i] * nd[i]);  // colors.py:234-237: df/mx
-#if defined(CURL_R2_HSV)
-    s = keep_if(live, s);
-#else
     if (!UNIT) s = keep_if(live, s);     // 0 when df == 0 (UNIT: nd == 0 and a finite q give exactly 0)
-#endif
     p.c0[i] = UNIT ? h : clampf(h, kHsvFloor, 1.0f);  // colors.py:240
     p.c1[i] = UNIT ? s : clampf(s, kHsvFloor, 1.0f);
     p.c2[i] = UNIT ? mx[i] : clampf(mx[i], kHsvFloor, 1.0f);
@@ -795,15 +645,6 @@ template <bool UNIT = false>  // UNIT: h, s, v already in [0,1] (straight out of
 CURL_HD Px hsv2rgb(Px p) {
   // colors.py:141-175 in sextant units: clamp(360h - a, 0, 60) * (d/60) == clamp(6h - a/60, 0, 1) * d,
   // so every ramp is one saturating add (v_add_f32 ... clamp) and the /60 disappears.
-#if defined(CURL_R2_HSV)  // A/B build (tools/variants.py): the round-2 form, two ramps and two fmas per channel
-  float h = (UNIT ? p.c0 : clamp01(p.c0)) * vconst(6.0f), s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
-  float q = v * (1.0f - s);
-  float d = v - q;
-  // the reference's identically-zero terms (m1,m3,m5 = 0) add +0 and are dropped
-  float r = fmaf(clamp01(h - 4.0f), d, fmaf(clamp01(h - 1.0f), -d, v));   // colors.py:144-150
-  float g = fmaf(clamp01(h - 3.0f), -d, fmaf(clamp01(h), d, q));          // colors.py:153-159
-  float b = fmaf(clamp01(h - 5.0f), -d, fmaf(clamp01(h - 2.0f), d, q));   // colors.py:163-168
-#else
   // Each channel's two ramps are one trapezoid: for h6 = 6h in [0,6]
   //   clamp(h6-1) - clamp(h6-4) = clamp(2 - |h6-3|),  clamp(h6) - clamp(h6-3) = clamp(2 - |h6-2|),
   //   clamp(h6-2) - clamp(h6-5) = clamp(2 - |h6-4|)   (rise, plateau at 1, fall),
@@ -813,13 +654,12 @@ CURL_HD Px hsv2rgb(Px p) {
   const float hh = UNIT ? p.c0 : clamp01(p.c0), s = UNIT ? p.c1 : clamp01(p.c1), v = UNIT ? p.c2 : clamp01(p.c2);
   const float d = v * s;   // v - p, p = v (1 - s): colors.py:142
   const float q = v - d;
-  const float tr = clamp01(2.0f - fabsf(fmaf(hh, vconst(6.0f), -3.0f)));
-  const float tg = clamp01(2.0f - fabsf(fmaf(hh, vconst(6.0f), -2.0f)));
-  const float tb = clamp01(2.0f - fabsf(fmaf(hh, vconst(6.0f), -4.0f)));
+  const float tr = clamp01(2.0f - fabsf(fmaf(hh, 6.0f, -3.0f)));
+  const float tg = clamp01(2.0f - fabsf(fmaf(hh, 6.0f, -2.0f)));
+  const float tb = clamp01(2.0f - fabsf(fmaf(hh, 6.0f, -4.0f)));
   float r = fmaf(tr, -d, v);   // colors.py:144-150
   float g = fmaf(tg, d, q);    // colors.py:153-159
   float b = fmaf(tb, d, q);    // colors.py:163-168
-#endif
   Px o;
   o.c0 = clamp01(r);
   o.c1 = clamp01(g);

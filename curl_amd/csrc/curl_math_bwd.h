@@ -175,7 +175,7 @@ CURL_HD Px rgb2lab_t(Px p, Rgb2LabT& t) {
   for (int c = 0; c < 3; ++c) e[c] *= kGammaFrac;
   for (int c = 0; c < 3; ++c) e[c] = hw_exp2(e[c]);  // u^0.4
   CURL_TRANS_END();
-  const float k_lin = vconst(kInv1292), k_pow = (float)2.4 * kInv1055;
+  const float k_lin = kInv1292, k_pow = (float)2.4 * kInv1055;
   for (int c = 0; c < 3; ++c) {
     const lmask lo = lm_le_u(x[c], kSrgbThr);  // the linear branch (colors.py:37)
     const float ue = u[c] * e[c];              // u^1.4: d u^2.4 / du = 2.4 u^1.4
@@ -191,7 +191,7 @@ CURL_HD Px rgb2lab_t(Px p, Rgb2LabT& t) {
   for (int r = 0; r < 3; ++r) f[r] = hw_exp2(lg[r] * kThird);                     // t^(1/3)
   for (int r = 0; r < 3; ++r) t.df3[r] = hw_exp2(lg[r] * (float)(-2.0 / 3.0));    // t^(-2/3) = 3 d t^(1/3) / dt
   CURL_TRANS_END();
-  const float k_df = vconst(3.0f * kInv3Eps2);
+  const float k_df = (3.0f * kInv3Eps2);
   for (int r = 0; r < 3; ++r) {
     const lmask lo = lm_le_u(tt[r], kEps3);  // colors.py:45-47
     f[r] = lm_sel(lo, fmaf(tt[r], kInv3Eps2, k4_29), f[r]);
@@ -227,7 +227,7 @@ CURL_HD Px lab2rgb_t(Px p, Lab2RgbT& t) {
   const float f[3] = {fmaf(p.c1, (float)(220.0 / 500.0), fy - (float)(110.0 / 500.0)), fy,
                       fmaf(p.c2, (float)(-220.0 / 200.0), fy + (float)(110.0 / 200.0))};
   float X[3], v[3], pw[3], rv[3];
-  const float k_dx = vconst(k3Eps2 * (float)(1.0 / 3.0));
+  const float k_dx = (k3Eps2 * (float)(1.0 / 3.0));
   for (int i = 0; i < 3; ++i) {
     const lmask lo = lm_le_u(f[i], kEps);  // colors.py:110-111
     const float f2 = f[i] * f[i];
@@ -242,7 +242,7 @@ CURL_HD Px lab2rgb_t(Px p, Lab2RgbT& t) {
   for (int r = 0; r < 3; ++r) pw[r] = hw_exp2(pw[r] * kInvGamma);  // v^(1/2.4)
   for (int r = 0; r < 3; ++r) rv[r] = hw_rcp(v[r]);
   CURL_TRANS_END();
-  const float k_dn = vconst((float)(12.92 * 2.4 / 1.055));
+  const float k_dn = (float)(12.92 * 2.4 / 1.055);
   float o[3];
   for (int r = 0; r < 3; ++r) {
     const lmask lo = lm_le_u(v[r], kLinThr);  // colors.py:118-119

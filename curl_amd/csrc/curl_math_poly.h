@@ -10,9 +10,7 @@
 // ~2.6 kFLOP per pixel: this kernel is VALU-bound by a wide margin (no MFMA shape fits: the contraction has
 // 3 output columns per 126-deep dot product, 3/16 of the smallest f32 MFMA tile, at the VALU's own rate).
 #pragma once
-#ifndef CURL_POLY_SEL
-#define CURL_POLY_SEL 0  // the converters' threshold selects inside the polynomial model: 0 eager; 2 (predicated) spills 688 B per lane at the kernel's 128-VGPR budget, 1 (skipped per wave too) 1.1 KB -- round 3
-#endif
+constexpr int kPolySel = 0;  // the converters' threshold selects inside the polynomial model: 0 eager; 2 (predicated) spills 688 B per lane at the kernel's 128-VGPR budget, 1 (skipped per wave too) 1.1 KB -- round 3
 #include "curl_math_bwd.h"
 
 namespace curlm {
@@ -66,9 +64,6 @@ struct PolyCoef<curl_f2> {
   }
   template <int QA, int QB>
   static __device__ __forceinline__ curl_f2 fma_cc(const float* c, curl_f2 v) {
-#if defined(CURL_POLY_SPLAT_FIRST)  // experiment build: the round-1 form (broadcast built by the compiler)
-    return poly_fmav(splat2(c[QA]), v, splat2(c[QB]));
-#endif
     const curl_f2 a = pair(c, QA), b = pair(c, QB);
     curl_f2 r;
     if constexpr ((QA & 1) == 0 && (QB & 1) == 0)
@@ -83,9 +78,6 @@ struct PolyCoef<curl_f2> {
   }
   template <int QA>
   static __device__ __forceinline__ curl_f2 fmav_c(const float* c, curl_f2 v, curl_f2 t) {
-#if defined(CURL_POLY_SPLAT_FIRST)
-    return poly_fmav(splat2(c[QA]), v, t);
-#endif
     const curl_f2 a = pair(c, QA);
     curl_f2 r;
     if constexpr ((QA & 1) == 0)
@@ -162,7 +154,6 @@ CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float*
         v[q][k].x = vars[k][2 * q];
         v[q][k].y = vars[k][2 * q + 1];
       }
-    CURL_POLY_BEGIN();  // packed code: never pairs with another wave's instruction (curl_math.h, issue priority)
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
       CURL_FENCE();
@@ -173,7 +164,6 @@ CURL_HD void poly3_n(float (&out)[3][N], const float (&vars)[V][N], const float*
         out[o][2 * q + 1] = r[q].y;
       }
     }
-    CURL_POLY_END();
     CURL_FENCE();
   }
   if (N & 1) {
@@ -223,7 +213,7 @@ template <int V, int N, bool SEQ = false>
 CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], const float* coef, bool residual_only) {
   constexpr int NC = SEQ ? PolyEval<V>::kSeqStride : PolyEval<V>::kCoeffs;
   PxN<N> lab = p, hsv = p;
-  rgb2lab_n<N, CURL_POLY_SEL>(lab);
+  rgb2lab_n<N, kPolySel>(lab);
   rgb2hsv_n<N>(hsv);
   float vars[V][N], o[3][N];
   float res[3][N];
@@ -265,7 +255,7 @@ CURL_HD void trispace_n(PxN<N>& p, const float (&xw)[N], const float (&yh)[N], c
     PxN<N> q;
 #pragma unroll
     for (int i = 0; i < N; ++i) q.c0[i] = o[0][i], q.c1[i] = o[1][i], q.c2[i] = o[2][i];
-    lab2rgb_n<N, false, CURL_POLY_SEL>(q);
+    lab2rgb_n<N, false, kPolySel>(q);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       res[0][i] += 2.0f * (q.c0[i] - 0.5f);

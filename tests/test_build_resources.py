@@ -2,14 +2,24 @@
 a GPU, ~25 s).  Round 3 lost 6.7x on the polynomial path for one run because a change in a shared header made its kernel
 spill 1.1 KB per lane -- no test saw it, only the bench did.  This one does: no product kernel may use scratch memory, and
 the occupancy-defining VGPR counts are pinned (8 waves per SIMD for the fused curve kernels, 4 for the polynomial model,
-3 for the layer backward)."""
+3 for the layer backward).
+
+Round 4: the experiment switches of rounds 1-3 were taken out of curl_amd/csrc (they live on as
+tools/experiments/patches/).  Two tripwires keep it that way: the set of CURL_* macro names the product sources may
+mention is closed (a new -D switch has to be put on the list deliberately), and the instruction counts of the three hot
+kernels are pinned to the values the clean-up left unchanged (tools/isa_fingerprint.py showed all 246 kernels
+bit-identical before / after) -- a deliberate kernel change updates the numbers in the same commit."""
+import glob
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
 from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -24,7 +34,9 @@ def kernels(tmp_path_factory):
     subprocess.check_call([HIPCC] + flags + ["-S", "--cuda-device-only", "-o", str(out), B.SRC],
                           stderr=subprocess.DEVNULL)
     res = {}
-    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", out.read_text(), flags=re.S):
+    global _ASM
+    _ASM = out.read_text()
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", _ASM, flags=re.S):
         body = m.group(2)
         res[m.group(1)] = (int(re.search(r"next_free_vgpr (\d+)", body).group(1)),
                            int(re.search(r"private_segment_fixed_size (\d+)", body).group(1)))
@@ -49,3 +61,61 @@ def test_vgpr_budget(kernels, frag, max_vgprs):
     assert hits, frag
     for k, (vgprs, _) in hits.items():
         assert vgprs <= max_vgprs, (k, vgprs)
+
+
+_ASM = None
+
+# every CURL_* name the product sources and the public header may mention: the C ABI's constants, the host-twin switch,
+# and function-like helpers.  No `#ifndef`-overridable tuning knobs, no experiment switches.
+ALLOWED_MACROS = {
+    # include/curl_hip.h: the ABI
+    "CURL_HIP_H", "CURL_OK", "CURL_MAX_KNOTS", "CURL_K_UNEVEN", "CURL_MASK_NONE", "CURL_MASK_U8", "CURL_MASK_F32",
+    "CURL_E_NULL", "CURL_E_SHAPE", "CURL_E_KNOTS", "CURL_E_MASK", "CURL_E_FLAGS", "CURL_E_WORKSPACE",
+    "CURL_F_EXACT_ORDER", "CURL_F_PWL", "CURL_F_RESIDUAL_ONLY", "CURL_F_WS_READY", "CURL_F_MASK_FIRST",
+    "CURL_F_TUNE_UNROLL_SHIFT", "CURL_F_TUNE_UNROLL_MASK", "CURL_F_TUNE_BLOCK_SHIFT", "CURL_F_TUNE_BLOCK_MASK",
+    "CURL_F_TUNE_XCD", "CURL_F_TUNE_XCD_SHIFT", "CURL_F_TUNE_XCD_MASK", "CURL_F_TUNE_OCC", "CURL_F_TUNE_OCC_SHIFT",
+    "CURL_F_TUNE_OCC_MASK", "CURL_F_TUNE_NO_NT", "CURL_F_DIAG_NO_MEM", "CURL_F_DIAG_SKIP_PREP",
+    # the host twin of the arithmetic headers (tests/twin/curl_twin.cpp is compiled with -DCURL_HOST_TWIN)
+    "CURL_HOST_TWIN", "CURL_HD",
+    # function-like helpers
+    "CURL_FENCE", "CURL_SETPRIO", "CURL_TRANS_BEGIN", "CURL_TRANS_END", "CURL_LM_CMP",
+    # the generated Horner scheme's vocabulary (tools/gen_poly_horner.py -> csrc/poly_horner.inc)
+    "CURL_POLY_C", "CURL_POLY_EACH", "CURL_POLY_FMA", "CURL_POLY_FMAV", "CURL_POLY_FMAV_C", "CURL_POLY_FMA_CC",
+    "CURL_POLY_SPLAT",
+}
+
+
+def test_no_unknown_switch_in_the_product_sources():
+    files = glob.glob(os.path.join(ROOT, "curl_amd", "csrc", "**", "*.*"), recursive=True) + \
+        [os.path.join(ROOT, "include", "curl_hip.h")]
+    seen = {}
+    for f in files:
+        if not f.endswith((".h", ".hip", ".inc")):
+            continue
+        for name in set(re.findall(r"\bCURL_[A-Z0-9_]*[A-Z0-9]\b", open(f).read())):
+            seen.setdefault(name, os.path.relpath(f, ROOT))
+    unknown = {k: v for k, v in seen.items() if k not in ALLOWED_MACROS}
+    assert not unknown, f"CURL_* names outside the closed list (experiment switch? add it deliberately): {unknown}"
+    # ... and nothing in the product sources is conditional on a CURL_* macro except the host-twin switch
+    for f in files:
+        if f.endswith((".h", ".hip", ".inc")):
+            for ln in open(f).read().splitlines():
+                if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", ln) and "CURL_" in ln:
+                    assert re.search(r"CURL_(HOST_TWIN|HIP_H)\b", ln), (os.path.relpath(f, ROOT), ln)
+
+
+# (n_inst, n_valu, n_transcendental) of the kernel's whole code object, as tools/isa_fingerprint.py counts them
+PINNED_ISA = {
+    "_Z13stream_kernelI7OpLayerLi4ELi1ELi1ELb1ELi0ELb0EEv10StreamArgs": (1937, 1374, 152),
+    "_Z13stream_kernelI10OpLabStageLi4ELi1ELi1ELb1ELi0ELb0EEv10StreamArgs": (1473, 918, 144),
+    "_Z16layer_bwd_kernelILi4ELi1EEv7BwdArgs": (2061, 1859, 104),
+}
+
+
+def test_hot_kernel_instruction_counts_are_pinned(kernels):
+    import isa_fingerprint
+    fp = isa_fingerprint.kernels_of(_ASM)
+    for name, want in PINNED_ISA.items():
+        assert name in fp, name
+        got = (fp[name]["n_inst"], fp[name]["n_valu"], fp[name]["n_trans"])
+        assert got == want, (name, got, want)

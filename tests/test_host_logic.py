@@ -320,6 +320,7 @@ def test_bench_workload_table_and_replayed_traffic():
         assert w["bound"] in ("hbm", "valu") and w["bpp"] > 0 and w["flop_px"] > 0, name
     assert bench.WORKLOADS["layer"]["bound"] == "hbm" and bench.WORKLOADS["layer"]["bpp"] == 25.0
     assert bench.WORKLOADS["trispace"]["bound"] == "valu"
-    traffic, src = bench.load_traffic("OpLayer")
+    assert "layer_8bit" in bench.WORKLOADS and bench.WORKLOADS["layer_8bit"]["frag"] == "OpLayer"
+    traffic, src, _util = bench.load_traffic("OpLayer")
     assert 1.15e9 < traffic < 1.3e9 and src.startswith("profiles/traffic_r") and "not this run" in src
-    assert bench.load_traffic("NoSuchKernel") == (None, None)
+    assert bench.load_traffic("NoSuchKernel", "no_such_workload") == (None, None, None)
