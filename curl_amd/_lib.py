@@ -19,6 +19,7 @@ F_TUNE_UNROLL_SHIFT = 8
 F_TUNE_BLOCK_SHIFT = 11
 F_TUNE_XCD_SHIFT = 13
 F_TUNE_OCC_SHIFT = 19  # resident workgroups per CU: 0 = per-operator default, 1 = no cap, 2..7
+F_TUNE_PREP_SHIFT = 23  # where the curves are collapsed: 0 = by launch size, 1 = a launch of its own, 2 = inside the kernel
 F_TUNE_NO_NT = 0x8000
 F_DIAG_NO_MEM = 0x10000
 F_DIAG_SKIP_PREP = 0x20000

@@ -44,15 +44,19 @@ static int hip_fail(hipError_t e, const char* where) {
 //   [0..19]  (a,b) of curve c at [2c],[2c+1]   (segment order: see prep kernel)
 //   [20..22] regulariser of segment 0,1,2 ; [23] total
 //   [24..26] lab2rgb(0,0,0): what the Lab stage yields where the mask is 0 (model.py:154-157)
+//   [29]     (uint) the row's stamp: which knot count / row stride a prep pass filled it for (ws_stamp)
 //   [32..)   exp'd knots of every curve, segment after segment
 // ------------------------------------------------------------------------------------------------
 #define WS_COEF 0
 #define WS_REG 20
 #define WS_MASKED 24
+#define WS_STAMP 29
 #define WS_KNOTS 32
 #define MAX_CURVES 10
 
 static inline unsigned ws_stride(int n_knots) { return WS_KNOTS + ((unsigned)(n_knots + 3) & ~3u); }
+// what a prepared workspace row says about itself: the knot count and row stride it was filled for
+__host__ __device__ static inline unsigned ws_stamp(unsigned n_knots, unsigned stride) { return 0x43550000u ^ (n_knots * 2654435761u) ^ stride; }
 
 // Knots per curve as the C ABI carries them (include/curl_hip.h, CURL_K_UNEVEN): K in the low 16 bits; the high 16 bits,
 // when non-zero, are the knot count of the segment's LAST curve -- what torch.chunk hands it when the parameter count does
@@ -71,12 +75,15 @@ struct PrepArgs {
   unsigned stride;
 };
 
-// One workgroup per image.  exp in float64 (rounded once to float32: the best estimate of torch.exp's
-// float32 result), slopes in float32 as the reference forms them (curves.py:19), every sum in float64.
-__global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
+// The curves of ONE image, by one 256-thread workgroup: exp in float64 (rounded once to float32: the best estimate of
+// torch.exp's float32 result), slopes in float32 as the reference forms them (curves.py:19), every sum in float64.
+//   store: write the image's workspace row (and reg_out): knots_prep_kernel's one workgroup per image -- or, when the
+//          streaming kernel collapses its curves itself (stream_selfprep_kernel), the image's first workgroup;
+//   head:  NULL, or 32 floats of LDS that receive the row's head (coefficients, regularisers, masked-out colour) for the
+//          calling workgroup's own use.  Both forms run THIS code: their results are bit-identical.
+__device__ __forceinline__ void prep_image(const PrepArgs& a, unsigned b, bool store, float* head) {
   __shared__ float sC[MAX_CURVES * CURL_MAX_KNOTS];
   __shared__ float sReg[MAX_CURVES];
-  const unsigned b = blockIdx.x;
   float* ws = a.ws + (size_t)b * a.stride;
 
   int seg_off[4];
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     float r = raw_s[(size_t)b * per_img + local];
     float c = (float)exp((double)r);  // curves.py:54,106,153
     sC[i] = c;
-    ws[WS_KNOTS + i] = c;
+    if (store) ws[WS_KNOTS + i] = c;
   }
   __syncthreads();
   // one thread per curve
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
     const float* C = sC + off_s + local * KP_K(K_s);
     float ca, cb, creg;
     collapse_curve(C, K, ca, cb, creg);
-    ws[WS_COEF + 2 * c] = ca;
-    ws[WS_COEF + 2 * c + 1] = cb;
+    if (store) ws[WS_COEF + 2 * c] = ca, ws[WS_COEF + 2 * c + 1] = cb;
+    if (head) head[WS_COEF + 2 * c] = ca, head[WS_COEF + 2 * c + 1] = cb;
     sReg[c] = creg;
   }
   __syncthreads();
@@ -125,17 +132,22 @@ __global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) {
       float r = 0.0f;
       for (int k = curve0[s]; k < curve0[s + 1]; ++k) r += sReg[k];  // reg += per curve (curves.py:24)
       seg_reg[s] = r;
-      ws[WS_REG + s] = r;
     }
     tot = (seg_reg[0] + seg_reg[1]) + seg_reg[2];  // model.py:172-174 (rgb + lab) + hsv
-    ws[WS_REG + 3] = tot;
-    if (a.reg_out) a.reg_out[b] = tot;
     Px z = lab_stage_masked_out();
-    ws[WS_MASKED + 0] = z.c0;
-    ws[WS_MASKED + 1] = z.c1;
-    ws[WS_MASKED + 2] = z.c2;
+    if (store) {
+      ws[WS_REG + 0] = seg_reg[0], ws[WS_REG + 1] = seg_reg[1], ws[WS_REG + 2] = seg_reg[2], ws[WS_REG + 3] = tot;
+      if (a.reg_out) a.reg_out[b] = tot;
+      ws[WS_MASKED + 0] = z.c0, ws[WS_MASKED + 1] = z.c1, ws[WS_MASKED + 2] = z.c2;
+      // the row's identity, which CURL_F_WS_READY callers are checked against (knots_bwd_kernel)
+      reinterpret_cast<unsigned*>(ws)[WS_STAMP] = ws_stamp((unsigned)n_total, a.stride);
+    }
+    if (head) head[WS_MASKED + 0] = z.c0, head[WS_MASKED + 1] = z.c1, head[WS_MASKED + 2] = z.c2;
   }
 }
+
+// One workgroup per image (the two-launch form: every knot-driven entry point runs this first for large launches).
+__global__ __launch_bounds__(256) void knots_prep_kernel(PrepArgs a) { prep_image(a, blockIdx.x, true, nullptr); }
 
 #include "kernels/stream.inc"
 #include "kernels/ops.inc"

@@ -88,6 +88,14 @@ enum {
                                       and, where all of them are zero, never reads its pixels.  Forward: +0.5 ... +0.8 % on an
                                       all-ones mask, -7 % at 70 % coverage, -25 % at 40 %.  Same results
                                       bit for bit.  Ignored where it does not apply (other mask kinds, scalar kernels). */
+#define CURL_F_TUNE_PREP_SHIFT 23
+#define CURL_F_TUNE_PREP_MASK 0x1800000u /* where the image's curves are collapsed (exp, slopes, the (a, b) pairs): 0 = the library's
+                                            choice -- INSIDE the streaming kernel for launches small enough to be resident in
+                                            one or two rounds (one launch instead of two: one frame, the training crop batch),
+                                            in a launch of their own (one workgroup per image) otherwise; 1 = always the
+                                            separate launch; 2 = always in the kernel (where the entry point has that form).
+                                            Forward: curl_layer_fwd(_slab)_f32, curl_lab_stage_f32, curl_hsv_stage_f32,
+                                            curl_adjust_*_f32 (affine form).  Results are bit-identical either way. */
 #define CURL_F_DIAG_NO_MEM 0x10000u   /* DIAGNOSTICS ONLY: inputs synthesised in registers, stores suppressed --
                                          times the arithmetic alone; the output buffer is left untouched */
 

@@ -39,10 +39,10 @@ def test_constants_match_header():
     assert int(defs["CURL_F_DIAG_NO_MEM"], 16) == _lib.F_DIAG_NO_MEM
     assert int(defs["CURL_F_MASK_FIRST"], 16) == _lib.F_MASK_FIRST
     assert int(defs["CURL_F_WS_READY"], 16) == _lib.F_WS_READY and int(defs["CURL_F_DIAG_SKIP_PREP"], 16) == _lib.F_DIAG_SKIP_PREP
-    for name in ("UNROLL", "BLOCK", "XCD", "OCC"):   # tuning fields: shift and mask agree, fields do not overlap each other or the flags
+    for name in ("UNROLL", "BLOCK", "XCD", "OCC", "PREP"):   # tuning fields: shift and mask agree, fields do not overlap each other or the flags
         shift, mask = int(defs[f"CURL_F_TUNE_{name}_SHIFT"]), int(defs[f"CURL_F_TUNE_{name}_MASK"], 16)
         assert shift == getattr(_lib, f"F_TUNE_{name}_SHIFT") and mask >> shift << shift == mask and (mask >> shift) & 1
-    fields = [int(defs[f"CURL_F_TUNE_{n}_MASK"], 16) for n in ("UNROLL", "BLOCK", "XCD", "OCC")] + [
+    fields = [int(defs[f"CURL_F_TUNE_{n}_MASK"], 16) for n in ("UNROLL", "BLOCK", "XCD", "OCC", "PREP")] + [
         int(defs[n], 16) for n in ("CURL_F_EXACT_ORDER", "CURL_F_PWL", "CURL_F_RESIDUAL_ONLY", "CURL_F_TUNE_NO_NT", "CURL_F_DIAG_NO_MEM",
                                     "CURL_F_DIAG_SKIP_PREP", "CURL_F_WS_READY", "CURL_F_MASK_FIRST")]
     assert sum(fields) == __import__("functools").reduce(lambda a, b: a | b, fields), "flag bits overlap"

@@ -74,7 +74,7 @@ ALLOWED_MACROS = {
     "CURL_F_EXACT_ORDER", "CURL_F_PWL", "CURL_F_RESIDUAL_ONLY", "CURL_F_WS_READY", "CURL_F_MASK_FIRST",
     "CURL_F_TUNE_UNROLL_SHIFT", "CURL_F_TUNE_UNROLL_MASK", "CURL_F_TUNE_BLOCK_SHIFT", "CURL_F_TUNE_BLOCK_MASK",
     "CURL_F_TUNE_XCD", "CURL_F_TUNE_XCD_SHIFT", "CURL_F_TUNE_XCD_MASK", "CURL_F_TUNE_OCC", "CURL_F_TUNE_OCC_SHIFT",
-    "CURL_F_TUNE_OCC_MASK", "CURL_F_TUNE_NO_NT", "CURL_F_DIAG_NO_MEM", "CURL_F_DIAG_SKIP_PREP",
+    "CURL_F_TUNE_OCC_MASK", "CURL_F_TUNE_PREP", "CURL_F_TUNE_PREP_SHIFT", "CURL_F_TUNE_PREP_MASK", "CURL_F_TUNE_NO_NT", "CURL_F_DIAG_NO_MEM", "CURL_F_DIAG_SKIP_PREP",
     # the host twin of the arithmetic headers (tests/twin/curl_twin.cpp is compiled with -DCURL_HOST_TWIN)
     "CURL_HOST_TWIN", "CURL_HD",
     # function-like helpers

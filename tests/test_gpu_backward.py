@@ -525,3 +525,65 @@ def test_foreground_masks_skip_masked_out_wavefronts(ops, dev):
     o, r = layer(xs, d[1], Ld, Rd, Hd)
     ((o * d[5]).sum() + (r * d[6]).sum()).backward()
     assert torch.equal(o, out0) and torch.equal(xs.grad, a[0]) and torch.equal(Ld.grad, a[1]) and torch.equal(Hd.grad, a[3])
+
+
+# ------------------------------------------------------------------ one launch per call
+PREP_SEPARATE, PREP_IN_KERNEL = 1 << 23, 2 << 23
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 64), (3, 7, 9), (1, 256, 256), (32, 32, 32)])
+def test_curve_collapse_placement_is_bit_identical(ops, dev, shape):
+    """CURL_F_TUNE_PREP: the image's curves collapsed in a launch of their own (knots_prep_kernel, one workgroup per image) or
+    inside the streaming kernel by every workgroup (stream_selfprep_kernel; the library's choice for small launches).  The
+    same device code runs either way: images, regularisers and the workspace row are BIT-identical, for every mask kind, on
+    the float4 and the scalar paths, and the backward computes the same gradients from either row."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * H + W)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    gout = torch.rand(B, 3, H, W, generator=g).to(dev)
+    greg = torch.rand(B, generator=g).to(dev)
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.2).to(dev) for n in (48, 48, 64))
+    holes = (torch.rand(B, 1, H, W, generator=g) > 0.3).to(dev)
+    for mask in (None, holes, holes.float() * 0.7):
+        o1, r1, w1 = ops.curl_layer_forward(img, mask, L, R, Hk, flags=PREP_SEPARATE, return_workspace=True)
+        o2, r2, w2 = ops.curl_layer_forward(img, mask, L, R, Hk, flags=PREP_IN_KERNEL, return_workspace=True)
+        o0, r0 = ops.curl_layer_forward(img, mask, L, R, Hk)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(o0, o1) and torch.equal(r0, r1)
+        # every slot of the row a prep pass writes: (a, b) pairs, regularisers, masked-out colour, stamp, knots
+        cols = list(range(0, 27)) + [29] + list(range(32, 32 + 160))
+        assert torch.equal(w1.view(torch.int32).view(B, -1)[:, cols], w2.view(torch.int32).view(B, -1)[:, cols])
+        for fn, k in ((ops.lab_stage, L), (ops.hsv_stage, Hk)):
+            a, ra = fn(img, mask, k, flags=PREP_SEPARATE)
+            b, rb = fn(img, mask, k, flags=PREP_IN_KERNEL)
+            assert torch.equal(a, b) and torch.equal(ra, rb)
+        # the backward takes the workspace row of either form (CURL_F_WS_READY): the same gradients, bit for bit
+        want = ops.curl_layer_backward(img, mask, L, R, Hk, gout, greg, workspace=w1)
+        got = ops.curl_layer_backward(img, mask, L, R, Hk, gout, greg, workspace=w2)
+        none = ops.curl_layer_backward(img, mask, L, R, Hk, gout, greg)  # no workspace: the backward's own prep launch
+        for x, y, z in zip(got, want, none):
+            assert torch.equal(x, y) and torch.equal(z, y)
+    for fn, k in ((ops.adjust_rgb, R), (ops.adjust_lab, L), (ops.adjust_hsv, Hk)):
+        a, ra = fn(img, k, flags=PREP_SEPARATE)
+        b, rb = fn(img, k, flags=PREP_IN_KERNEL)
+        assert torch.equal(a, b) and torch.equal(ra, rb)
+
+
+def test_backward_refuses_a_workspace_nobody_filled(ops, dev):
+    """CURL_F_WS_READY trusts the caller.  A workspace row that no prep pass filled for these knot counts (zeros, or
+    the row of a call with other K) is answered with NaN knot gradients, not with plausible numbers."""
+    B, H, W = 2, 16, 16
+    g = torch.Generator().manual_seed(3)
+    img, gout = (torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(2))
+    L, R, Hk = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (48, 48, 64))
+    _, _, ws = ops.curl_layer_forward(img, None, L, R, Hk, return_workspace=True)
+    ok = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=ws)
+    assert all(torch.isfinite(t).all() for t in ok[1:])
+    bad = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=torch.zeros_like(ws))
+    assert all(torch.isnan(t).all() for t in bad[1:])
+    # the row of a forward with other knot counts (K = 8): same size class, another stamp
+    L8, R8, H8 = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (24, 24, 32))
+    _, _, ws8 = ops.curl_layer_forward(img, None, L8, R8, H8, return_workspace=True)
+    big = torch.zeros_like(ws)
+    big[:ws8.numel()] = ws8
+    bad = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=big)
+    assert all(torch.isnan(t).all() for t in bad[1:])
