@@ -513,7 +513,7 @@ def load_traffic(kernel_fragment, workload=None):
             except Exception:
                 continue
             for key in (workload, kernel_fragment):
-                if key in d:
+                if key is not None and key in d:
                     return (d[key]["hbm_bytes_per_launch"], f"profiles/{f} (builder's rocprofv3 --pmc pass, not this run)",
                             d[key].get("valu_issue_util"))
     return None, None, None
@@ -609,8 +609,10 @@ def main():
         gbps = npx_rank * bpp / (dev_ms * 1e-3) / 1e9
         tflops = npx_rank * w["flop_px"] / (dev_ms * 1e-3) / 1e12
         # the PMC passes were taken at bs32 (the CONFIG5 rows: at their own image counts, which B = 32 leaves as they are)
-        traffic, traffic_src, valu_util = (load_traffic(w["frag"], name) if B == 32 and not name.endswith("mask_first")
-                                           else (None, None, None))
+        # (a kernel-fragment entry stands for the float32 forward workloads of that kernel only: the byte-edge rows and the
+        # mask-first variant move other bytes)
+        traffic, traffic_src, valu_util = (load_traffic(w["frag"] if bpp >= 24.0 and not name.endswith("mask_first") else None, name)
+                                           if B == 32 else (None, None, None))
         hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                "frac_of_measured_copy_ceiling_6585": gbps / COPY_CEILING_GBPS}
         valu = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,

@@ -521,3 +521,35 @@ def input_sensitivity(img, mask, L, R, H, r64=None, h=1e-6):
             o, _ = curl_layer(p, mask, L, R, H)
             S = torch.maximum(S, (o - r64).abs().amax(1) / h)
     return S
+
+
+def layer_gradients(img, mask, L, R, H, w, wr=None, dtype=torch.float64):
+    """Autograd of curl_layer (the reference's arithmetic, model.py:137-176) for the loss sum(out * w) + sum(reg * wr),
+    evaluated in `dtype`.  -> (d img, d L, d R, d H).  The float64 evaluation is the backward's parity yardstick."""
+    x = img.detach().to(dtype).clone().requires_grad_(True)
+    Lk, Rk, Hk = (t.detach().to(dtype).clone().requires_grad_(True) for t in (L, R, H))
+    out, reg = curl_layer(x, mask.to(dtype), Lk, Rk, Hk)
+    loss = (out * w.to(dtype)).sum()
+    if wr is not None:
+        loss = loss + (reg * wr.to(dtype)).sum()
+    loss.backward()
+    return x.grad, Lk.grad, Rk.grad, Hk.grad
+
+
+def gradient_curvature(img, mask, L, R, H, w, g64=None, h=1e-6):
+    """How fast the image gradient itself changes with the input, per pixel: max over the three channels and both signs of
+    |d img(x +- h e_k) - d img(x)| / h, float64 -- the backward's counterpart of input_sensitivity.  A float32 evaluation of
+    the chain sees its intermediates perturbed by roundings worth ~1e-6 of input; its gradient can be off by that times this
+    curvature.  A pixel whose value h * curvature is a sizeable fraction of the gradient scale sits within h of a clamp gate, a
+    threshold or a channel tie -- a DISCONTINUITY of the gradient: the exception set of tests/test_gpu_backward.py.
+    -> [B,H,W] float64."""
+    if g64 is None:
+        g64 = layer_gradients(img, mask, L, R, H, w)[0]
+    C = torch.zeros(g64.shape[0], g64.shape[2], g64.shape[3], dtype=torch.float64)
+    for k in range(3):
+        for sgn in (1.0, -1.0):
+            p = img.double().clone()
+            p[:, k] += sgn * h
+            gp = layer_gradients(p, mask, L, R, H, w)[0]
+            C = torch.maximum(C, (gp - g64).abs().amax(1) / h)
+    return C

@@ -31,8 +31,13 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-@pytest.mark.parametrize("sig,tol", [("s01", 2e-4), ("s05", 5e-3)])
-def test_golden_gradients(ops, dev, golden, sig, tol):
+@pytest.mark.parametrize("sig,tol_knots,tol_img", [("s01", 5e-6, 2e-5), ("s05", 1e-3, 1e-3)])
+def test_golden_gradients(ops, dev, golden, sig, tol_knots, tol_img):
+    """Golden gradients = float32 autograd through the REFERENCE's primitives (tests/golden/make_golden.py).  At sigma 0.1 the
+    host twin of this arithmetic is within 5.8e-7 (knots) / 4.2e-6 (image, of the gradient scale) of them; the bars are that
+    with room for the hardware transcendentals (round 3 asserted 2e-4 and only the 0.999 quantile of the image gradient).
+    At sigma 0.5 the golden's own distance from the float64 evaluation is 5e-5 of the scale: the precise statement there is
+    test_backward_parity_is_pinned_to_float64_autograd below."""
     c = golden("chain")
     args = [T(c[k], dev) for k in ("img",)]
     mask = T(c["mask_disk"], dev)
@@ -40,13 +45,80 @@ def test_golden_gradients(ops, dev, golden, sig, tol):
     w, wr = T(c[sig + "_grad_w"], dev), T(c[sig + "_grad_wr"], dev)
     for m in (mask, mask.float()):
         gi, gL, gR, gH = ops.curl_layer_backward(args[0], m, L, R, H, w, wr)
-        assert rel(gL, c[sig + "_grad_L"]) <= tol and rel(gR, c[sig + "_grad_R"]) <= tol
-        assert rel(gH, c[sig + "_grad_H"]) <= tol
+        assert rel(gL, c[sig + "_grad_L"]) <= tol_knots and rel(gR, c[sig + "_grad_R"]) <= tol_knots
+        assert rel(gH, c[sig + "_grad_H"]) <= tol_knots
         d = np.abs(gi.cpu().numpy() - c[sig + "_grad_img"])
         scale = np.abs(c[sig + "_grad_img"]).max()
-        assert np.quantile(d, 0.999) <= tol * scale and d.max() <= 20 * tol * scale
+        assert d.max() <= tol_img * scale, (float(d.max()), float(scale))
+        assert (gi.cpu().numpy()[:, :, ~c["mask_disk"][0, 0]] == 0).all()
     gi2, gL2, _, _ = ops.curl_layer_backward(args[0], mask, L, R, H, w, wr, need_grad_img=False)
     assert gi2 is None and torch.equal(gL2, gL)
+
+
+def _mosaic_8bit():
+    """24 rows of each of tools/synth8.py's eight content bands (gradients, grey ramps, flat dark patches with exact zeros,
+    tie palettes, photograph-like, saturated, dark photograph, checker), 256 columns: [1,3,192,256] on the k/255 grid."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth8
+    import curl_oracle as O
+    u8 = synth8.coherent_8bit_frames(1, 1000, 1500, seed=1)[0]
+    rows = np.concatenate([np.arange(125 * k + 50, 125 * k + 74) for k in range(8)])
+    return O.u8hwc_to_f32chw(np.ascontiguousarray(u8[rows][:, 200:456]))[None]
+
+
+@pytest.mark.parametrize("case", ["random_s01", "random_s03", "coherent_8bit_dim_knots"])
+def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
+    """the backward's parity pinned the way the forward's is.  Yardstick: FLOAT64 autograd through the
+    oracle (the reference's arithmetic).  Per pixel,
+        |d img_HIP - d img_64| <= max(2e-6 * G, 2e-6 * C(pixel)),     G = max |d img_64|,
+    C = the float64 gradient's own rate of change with the input (curl_oracle.gradient_curvature): a float32 chain perturbs
+    its intermediates by roundings worth ~1e-6 of input.  The EXCEPTION SET is identified, not averaged away: pixels where
+    the float64 gradient JUMPS within +-1e-6 of the input (h * C > 1e-3 * G: a clamp gate, a threshold select or a channel
+    tie of some intermediate within rounding distance) -- there float32 may legitimately take the other side; it is reported
+    and must be tiny.  Knot gradients (sums over all pixels): <= 2e-5 of their scale at sigma 0.1 (the host twin: 8e-7).
+    On the 8-bit mosaic -- exact ties, exact zeros, flat dark patches -- the subgradient conventions are exercised exactly AT
+    the discontinuities (torch's clamp passes the gradient at the bounds, the hue terms' masks are constants): they must match."""
+    import curl_oracle as O
+    g = torch.Generator().manual_seed(7)
+    if case == "coherent_8bit_dim_knots":
+        img = _mosaic_8bit()
+        B, _, H, W = img.shape
+        # curves that halve their channel: model.py:170's clamp(img + residual) does not saturate, every pixel carries gradient
+        L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 - 0.7 for n in (48, 48, 64))
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        mask = ((((yy - H / 2) / (H / 2)) ** 2 + ((xx - W / 2) / (W / 2)) ** 2) < 0.9)[None, None]
+        tol_knots = 2e-5
+    else:
+        B, H, W = 2, 96, 128
+        sigma = 0.1 if case == "random_s01" else 0.3
+        img = torch.rand(B, 3, H, W, generator=g)
+        L, R, Hk = (torch.randn(B, n, generator=g) * sigma for n in (48, 48, 64))
+        mask = torch.rand(B, 1, H, W, generator=g) > 0.1
+        tol_knots = 2e-5 if sigma == 0.1 else 2e-4
+    w = torch.randn(B, 3, H, W, generator=g)
+    wr = torch.rand(B, generator=g)
+    mf = mask.float()
+    g64, gL64, gR64, gH64 = O.layer_gradients(img, mf, L, R, Hk, w, wr)
+    assert float(g64.abs().max()) > 0.5 and float((g64.abs().amax(1) > 0).double().mean()) > 0.3   # not a saturated frame
+    C = O.gradient_curvature(img, mf, L, R, Hk, w, g64=g64, h=1e-6)
+    G = float(g64.abs().max())
+    for m in (mask, mf):
+        gi, gL, gR, gH = ops.curl_layer_backward(img.to(dev), m.to(dev), L.to(dev), R.to(dev), Hk.to(dev), w.to(dev), wr.to(dev))
+        for got, want in ((gL, gL64), (gR, gR64), (gH, gH64)):
+            assert rel(got, want) <= tol_knots, (case, rel(got, want))
+        d = (gi.cpu().double() - g64).abs().amax(1)
+        jump = 1e-6 * C > 1e-3 * G                       # a discontinuity of the float64 gradient within +-1e-6
+        bound = torch.clamp(2e-6 * C, min=2e-6 * G)
+        over = (d > bound) & ~jump
+        print(f"backward parity {case} mask={m.dtype}: max |err| {float(d.max()):.2e} of G {G:.2f}; max err/bound "
+              f"{float((d / bound)[~jump].max()):.2f}; exception set (gradient jump within 1e-6): {int(jump.sum())} of {jump.numel()} px")
+        assert int(over.sum()) == 0, (case, int(over.sum()), float((d / bound)[~jump].max()))
+        assert int(jump.sum()) <= 1e-3 * jump.numel()
+        assert float(d[jump].max() if bool(jump.any()) else 0.0) <= 2.0 * G    # even there: a gate flipped, nothing worse
+        assert (gi.cpu()[:, :, ~mask[0, 0]] == 0).all() if case == "coherent_8bit_dim_knots" else True
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 32), (1, 7, 9), (3, 33, 65)])
