@@ -589,7 +589,7 @@ def main():
         step = make_step(name, ops, masks, sets)
         npx_rank = workload_pixels(name, B)
         cold_us = cold_first_launch_us(step, sets, device) if cold else None
-        cold_ms = cold_start_run(step, sets, steps, warmup, device) if cold else None
+        cold_ms = cold_start_run(step, sets, steps, warmup, device) if cold and not args.no_extras else None
         wall, dev_ms, dev_ms_min = timed_run(step, sets, steps, warmup, dist, device)
         power = None
         if cold and rank == 0 and not args.no_extras:
@@ -633,6 +633,7 @@ def main():
                "device_ms_per_step_min_over_ranks": dev_ms_min, "roofline": roof}
         if cold_us is not None:
             res["cold_first_launch_us"] = cold_us
+        if cold_ms is not None:
             res["cold_start"] = {"ms_per_step": cold_ms, "value": npx_rank / (cold_ms * 1e-3) / 1e6, "unit": "Mpix/s per GPU",
                                  "protocol": f"0.5 s idle, {warmup} warm-up steps, {steps} timed steps, wall clock, no clock-settle "
                                              "launches (this rank alone)"}

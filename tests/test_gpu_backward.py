@@ -69,7 +69,7 @@ def _mosaic_8bit():
     return O.u8hwc_to_f32chw(np.ascontiguousarray(u8[rows][:, 200:456]))[None]
 
 
-@pytest.mark.parametrize("case", ["random_s01", "random_s03", "coherent_8bit_dim_knots"])
+@pytest.mark.parametrize("case", ["random_s01", "random_s03", "coherent_8bit_dim_knots", "fullsize_random_s01"])
 def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     """the backward's parity pinned the way the forward's is.  Yardstick: FLOAT64 autograd through the
     oracle (the reference's arithmetic).  Per pixel,
@@ -92,8 +92,9 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
         mask = ((((yy - H / 2) / (H / 2)) ** 2 + ((xx - W / 2) / (W / 2)) ** 2) < 0.9)[None, None]
         tol_knots = 2e-5
     else:
-        B, H, W = 2, 96, 128
-        sigma = 0.1 if case == "random_s01" else 0.3
+        # the full-size frame is where the exception set shows: ~15 gates per pixel x 1.5 M pixels within 1e-6 of one of them
+        B, H, W = (1, 1000, 1500) if case == "fullsize_random_s01" else (2, 96, 128)
+        sigma = 0.3 if case == "random_s03" else 0.1
         img = torch.rand(B, 3, H, W, generator=g)
         L, R, Hk = (torch.randn(B, n, generator=g) * sigma for n in (48, 48, 64))
         mask = torch.rand(B, 1, H, W, generator=g) > 0.1
@@ -105,10 +106,18 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     assert float(g64.abs().max()) > 0.5 and float((g64.abs().amax(1) > 0).double().mean()) > 0.3   # not a saturated frame
     C = O.gradient_curvature(img, mf, L, R, Hk, w, g64=g64, h=1e-6)
     G = float(g64.abs().max())
+    tol_seg = [tol_knots] * 3
+    if case == "fullsize_random_s01":
+        # a knot gradient is a sum over 1.5 M pixels, and on this frame ONE pixel of the exception set flips a gate in the
+        # reference's own float32 autograd (|d img| off by 3.7 of G = 26.7): its knot gradients are 2.5e-3 / 2.0e-4 / 2.7e-4
+        # from the float64 ones.  The kernel may be as far as the reference's float32 evaluation is, not farther.
+        ref32 = O.layer_gradients(img, mf, L, R, Hk, w, wr, dtype=torch.float32)
+        tol_seg = [max(tol_knots, 1.5 * rel(a, b)) for a, b in zip(ref32[1:], (gL64, gR64, gH64))]
+        print("reference float32 autograd vs float64, knot gradients:", [f"{rel(a, b):.2e}" for a, b in zip(ref32[1:], (gL64, gR64, gH64))])
     for m in (mask, mf):
         gi, gL, gR, gH = ops.curl_layer_backward(img.to(dev), m.to(dev), L.to(dev), R.to(dev), Hk.to(dev), w.to(dev), wr.to(dev))
-        for got, want in ((gL, gL64), (gR, gR64), (gH, gH64)):
-            assert rel(got, want) <= tol_knots, (case, rel(got, want))
+        for got, want, tol in zip((gL, gR, gH), (gL64, gR64, gH64), tol_seg):
+            assert rel(got, want) <= tol, (case, rel(got, want), tol)
         d = (gi.cpu().double() - g64).abs().amax(1)
         jump = 1e-6 * C > 1e-3 * G                       # a discontinuity of the float64 gradient within +-1e-6
         bound = torch.clamp(2e-6 * C, min=2e-6 * G)
