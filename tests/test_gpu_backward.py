@@ -69,7 +69,7 @@ def _mosaic_8bit():
     return O.u8hwc_to_f32chw(np.ascontiguousarray(u8[rows][:, 200:456]))[None]
 
 
-@pytest.mark.parametrize("case", ["random_s01", "random_s03", "coherent_8bit_dim_knots", "fullsize_random_s01"])
+@pytest.mark.parametrize("case", ["random_s01", "random_s03", "coherent_8bit_dim_knots", "cube_slices_8bit_dim_knots", "fullsize_random_s01"])
 def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     """the backward's parity pinned the way the forward's is.  Yardstick: FLOAT64 autograd through the
     oracle (the reference's arithmetic).  Per pixel,
@@ -80,10 +80,21 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     tie of some intermediate within rounding distance) -- there float32 may legitimately take the other side; it is reported
     and must be tiny.  Knot gradients (sums over all pixels): <= 2e-5 of their scale at sigma 0.1 (the host twin: 8e-7).
     On the 8-bit mosaic -- exact ties, exact zeros, flat dark patches -- the subgradient conventions are exercised exactly AT
-    the discontinuities (torch's clamp passes the gradient at the bounds, the hue terms' masks are constants): they must match."""
+    the discontinuities (torch's clamp passes the gradient at the bounds, the hue terms' masks are constants): they must match.
+    Sixteen slices of the 8-bit cube (1 M colours): the exception set is 14 colours -- black among them: L = 116 * (4/29) - 16
+    is zero up to rounding, the Lab curve's clamp gate at 0 is decided by the sign of a rounding error in ANY arithmetic."""
     import curl_oracle as O
     g = torch.Generator().manual_seed(7)
-    if case == "coherent_8bit_dim_knots":
+    if case == "cube_slices_8bit_dim_knots":
+        # sixteen slices of the 8-bit colour cube: every (r, g) pair at b = 0, 17, ..., 255 -- 1 048 576 colours, every exact
+        # r == g tie, black, white, every colour with a channel at 0 or 255
+        r8, g8, b8 = torch.meshgrid(torch.arange(256), torch.arange(256), torch.arange(0, 256, 17), indexing="ij")
+        img = (torch.stack((r8, g8, b8), 0).float() / 255).reshape(1, 3, 1024, 1024).contiguous()
+        B, _, H, W = img.shape
+        L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 - 0.7 for n in (48, 48, 64))
+        mask = torch.ones(B, 1, H, W, dtype=torch.bool)
+        tol_knots = 2e-5
+    elif case == "coherent_8bit_dim_knots":
         img = _mosaic_8bit()
         B, _, H, W = img.shape
         # curves that halve their channel: model.py:170's clamp(img + residual) does not saturate, every pixel carries gradient
@@ -106,20 +117,25 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     assert float(g64.abs().max()) > 0.5 and float((g64.abs().amax(1) > 0).double().mean()) > 0.3   # not a saturated frame
     C = O.gradient_curvature(img, mf, L, R, Hk, w, g64=g64, h=1e-6)
     G = float(g64.abs().max())
-    tol_seg = [tol_knots] * 3
-    if case == "fullsize_random_s01":
-        # a knot gradient is a sum over 1.5 M pixels, and on this frame ONE pixel of the exception set flips a gate in the
-        # reference's own float32 autograd (|d img| off by 3.7 of G = 26.7): its knot gradients are 2.5e-3 / 2.0e-4 / 2.7e-4
-        # from the float64 ones.  The kernel may be as far as the reference's float32 evaluation is, not farther.
-        ref32 = O.layer_gradients(img, mf, L, R, Hk, w, wr, dtype=torch.float32)
-        tol_seg = [max(tol_knots, 1.5 * rel(a, b)) for a, b in zip(ref32[1:], (gL64, gR64, gH64))]
-        print("reference float32 autograd vs float64, knot gradients:", [f"{rel(a, b):.2e}" for a, b in zip(ref32[1:], (gL64, gR64, gH64))])
+    jump = 1e-6 * C > 1e-3 * G                       # a discontinuity of the float64 gradient within +-1e-6 of the input
+    # Knot gradients are sums over all pixels, and one gate taken on the other side moves them by that pixel's whole
+    # contribution (on the cube slices: (79, 238, 34) alone moves d L by 1e-2 of its scale; on the full-size frame the
+    # reference's OWN float32 autograd flips one of the 17).  The statement that does not depend on which side of a kink a
+    # rounding falls: with the exception set masked out of both evaluations, the knot gradients agree to tol_knots.
+    mask_ex, want_knots = mask, (gL64, gR64, gH64)
+    if bool(jump.any()):
+        mask_ex = mask & ~jump[:, None]
+        want_knots = O.layer_gradients(img, mask_ex.float(), L, R, Hk, w, wr)[1:]
     for m in (mask, mf):
         gi, gL, gR, gH = ops.curl_layer_backward(img.to(dev), m.to(dev), L.to(dev), R.to(dev), Hk.to(dev), w.to(dev), wr.to(dev))
-        for got, want, tol in zip((gL, gR, gH), (gL64, gR64, gH64), tol_seg):
-            assert rel(got, want) <= tol, (case, rel(got, want), tol)
+        kn = (gL, gR, gH)
+        if bool(jump.any()):
+            mx = mask_ex if m.dtype == torch.bool else mask_ex.float()
+            kn = ops.curl_layer_backward(img.to(dev), mx.to(dev), L.to(dev), R.to(dev), Hk.to(dev), w.to(dev), wr.to(dev),
+                                         need_grad_img=False)[1:]
+        for got, want in zip(kn, want_knots):
+            assert rel(got, want) <= tol_knots, (case, rel(got, want), tol_knots)
         d = (gi.cpu().double() - g64).abs().amax(1)
-        jump = 1e-6 * C > 1e-3 * G                       # a discontinuity of the float64 gradient within +-1e-6
         bound = torch.clamp(2e-6 * C, min=2e-6 * G)
         over = (d > bound) & ~jump
         print(f"backward parity {case} mask={m.dtype}: max |err| {float(d.max()):.2e} of G {G:.2f}; max err/bound "

@@ -260,34 +260,71 @@ def test_every_8bit_colour_through_the_layer_and_the_stages(ops, dev, golden, kn
             print(f"8-bit cube {name}: max |err| {err:.2e}")
             assert err <= tol, (name, err)
 
-        def check(name, out, ref, sens):
-            d = (out.cpu().double() - ref.double()).abs().amax(1)[0]
+        def check(name, out, ref, fn64, tie_fn=None):
+            """fn64: the float64 stage on [1,3,1,P] pixels.  Offending colours (> 1e-5) must be explained, each one:
+            either ill-conditioned (S > 5 and error <= max(1e-5, 2e-6 * S), S by finite differences at h = 1e-6), or ON A
+            DISCONTINUITY OF THE REFERENCE: a step of the float64 result within 1e-5 of the colour (the
+            hue seam: the change at h = 1e-5 is at least half the change at h = 1e-4), or an EXACT TIE of the two largest
+            channels entering RGB2HSV -- colors.py:221-224 ADDS the hue terms there, an isolated point whose value (hue
+            120 deg for r == g > b) differs from the limit on both sides (60 deg): when two float32 intermediates are a
+            few ulp apart, the roundings of either implementation decide whether the tie happens.  tie_fn(px, gpu_value) says
+            whether the reference's own arithmetic, with those two intermediates set equal, gives the kernel's value."""
+            # SURVEY.md 8(d): err = |out - ref| / max(1, max |ref|) -- the Lab stage's output is not clamped (colors.py:121-123:
+            # config-1's curves take it to |values| of ~10), the layer's and the HSV stage's are in [0, 1]
+            scale = max(1.0, float(ref.abs().max()))
+            d = (out.cpu().double() - ref.double()).abs().amax(1)[0] / scale
             over = d > 1e-5
             n_over = int(over.sum())
-            worst = float(d.max())
-            msg = f"8-bit cube {name}: max |err| {worst:.2e}; exception set {n_over} of {d.numel()} colours over 1e-5"
+            msg = (f"8-bit cube {name}: max err {float(d.max()):.2e} (of max(1, max |ref|) = {scale:.2f}); exception set {n_over} of "
+                   f"{d.numel()} colours over 1e-5")
             if n_over:
                 ii = over.view(-1).nonzero()[:, 0]
                 px = x.view(1, 3, -1)[:, :, ii].reshape(1, 3, 1, -1).contiguous()
-                S = sens(px)[0, 0]
-                ratio = d.view(-1)[ii] / torch.clamp(2e-6 * S, min=1e-5)
-                msg += f" (their S: {float(S.min()):.0f} .. {float(S.max()):.0f}; max err / bound {float(ratio.max()):.2f})"
+                e = d.view(-1)[ii] * scale      # absolute again: the sensitivities below are absolute
+                S = _stage_sensitivity(fn64, px, 1e-6)[0, 0]
+                conditioned = (S > 5.0) & (e <= torch.clamp(2e-6 * S, min=1e-5))
+                step5 = _stage_sensitivity(fn64, px, 1e-5)[0, 0] * 1e-5     # |f(x +- 1e-5 e_k) - f(x)|, max over k and sign
+                step4 = _stage_sensitivity(fn64, px, 1e-4)[0, 0] * 1e-4
+                on_seam = ~conditioned & (step5 >= 0.5 * step4) & (step5 > 1e-3) & (e <= 1.5 * step5)
+                if tie_fn is not None:
+                    got = out.cpu().view(1, 3, -1)[:, :, ii]
+                    for j in (~(conditioned | on_seam)).nonzero()[:, 0].tolist():
+                        if tie_fn(px[:, :, :, j:j + 1], got[:, :, j]):
+                            on_seam[j] = True
+                msg += (f": {int(conditioned.sum())} ill-conditioned (S {float(S[conditioned].min()) if bool(conditioned.any()) else 0:.0f}"
+                        f" .. {float(S[conditioned].max()) if bool(conditioned.any()) else 0:.0f}), {int(on_seam.sum())} on a "
+                        f"discontinuity of the reference {[tuple(int(v) for v in cube.view(3, -1)[:, int(i)]) for i in ii[on_seam][:4]]}")
                 print(msg)
-                assert float(S.min()) > 5.0 and float(ratio.max()) <= 1.0, msg
+                assert bool((conditioned | on_seam).all()), msg
+                assert int(on_seam.sum()) <= 4, msg
             else:
                 print(msg)
             assert n_over <= max_frac * d.numel(), msg
 
-        m1 = lambda p: torch.ones(1, 1, *p.shape[2:])  # noqa: E731
+        m1 = lambda p: torch.ones(1, 1, *p.shape[2:], dtype=torch.float64)  # noqa: E731
+        L64, R64, H64 = L.double(), R.double(), Hk.double()
         out, _ = ops.lab_stage(xd, None, Ld)
-        check("lab_stage", out, O.lab_stage(x, ones, L)[0],
-              lambda p: _stage_sensitivity(lambda q: O.lab_stage(q, m1(q).double(), L.double())[0], p))
+        check("lab_stage", out, O.lab_stage(x, ones, L)[0], lambda q: O.lab_stage(q, m1(q), L64)[0])
         out, _ = ops.hsv_stage(xd, None, Hd)
-        check("hsv_stage", out, O.hsv_stage(x, ones, Hk)[0],
-              lambda p: _stage_sensitivity(lambda q: O.hsv_stage(q, m1(q).double(), Hk.double())[0], p))
+        check("hsv_stage", out, O.hsv_stage(x, ones, Hk)[0], lambda q: O.hsv_stage(q, m1(q), H64)[0])
         out, _ = ops.curl_layer_forward(xd, None, Ld, Rd, Hd)
         ref, _ = O.curl_layer(x, ones, L, R, Hk)
-        check("layer", out, ref, lambda p: O.input_sensitivity(p, m1(p), L, R, Hk))
+
+        def layer_tie(px, gpu_value):
+            """The reference's float32 chain up to RGB2HSV's input; if its two largest channels are within 16 ulp, set them
+            equal and finish the chain: does that reproduce the kernel's value to 1e-5?"""
+            one = torch.ones(1, 1, 1, 1)
+            rgb = O.adjust_rgb(O.lab_stage(px, one, L)[0], R)[0]        # model.py:151-160
+            v, order = rgb.flatten().sort(descending=True)
+            if float(v[0] - v[1]) > 16 * float(torch.finfo(torch.float32).eps) * float(v[0]):
+                return False
+            tied = rgb.clone()
+            tied.view(-1)[order[1]] = v[0]
+            res = O.hsv_stage(tied, one, Hk)[0]                          # model.py:163-169
+            want = torch.clamp(px + res, 0.0, 1.0)                       # model.py:170
+            return float((want.flatten() - gpu_value.flatten()).abs().max()) <= 1e-5
+
+        check("layer", out, ref, lambda q: O.curl_layer(q, m1(q), L64, R64, H64)[0], layer_tie)
         if knots != "bench":
             return
         # the fused byte path over the whole cube: bytes in, bytes out
@@ -295,9 +332,11 @@ def test_every_8bit_colour_through_the_layer_and_the_stages(ops, dev, golden, kn
         got, _ = ops.curl_layer_forward_u8hwc(u8, None, Ld, Rd, Hd)
         want = _ref_bytes(ref.numpy())
         diff = N(got) != want
+        # (the float path's exception set -- the one exact-tie colour above -- is not a byte-edge question: set aside)
+        excepted = ((out.cpu() - ref).abs().amax(1) > 1e-5)[0].numpy()[None, :, :, None]
         print(f"8-bit cube bytes: {int(diff.any(-1).sum())} of {n * n} colours differ from the truncated reference")
-        assert np.abs(N(got).astype(int) - want.astype(int)).max() <= 1
-        assert (~diff | _near_byte_boundary(ref.numpy(), 1e-4)).all() and int(diff.any(-1).sum()) <= 1e-4 * n * n
+        assert (np.abs(N(got).astype(int) - want.astype(int)) * ~excepted).max() <= 1
+        assert (~diff | _near_byte_boundary(ref.numpy(), 1e-5) | excepted).all() and int(diff.any(-1).sum()) <= 1e-4 * n * n
         assert torch.equal(got, ops.f32chw_to_u8hwc(out))
 
 
@@ -312,3 +351,25 @@ def _stage_sensitivity(fn64, px, h=1e-6):
             q[:, k] += sgn * h
             S = torch.maximum(S, (fn64(q) - base).abs().amax(1) / h)
     return S
+
+
+def test_polynomial_path_on_8bit_cube_slices(ops, dev):
+    """The fork's live per-pixel path (TriSpaceRegNet.generate_residual + generate_image, model.py:499-520; infer.py:44 feeds
+    it PIL bytes) on sixteen slices of the 8-bit colour cube -- every (r, g) pair at b = 0, 17, ..., 255: 1 048 576 colours, all
+    exact r == g ties, black, white -- against the oracle, float32 and fused uint8 entry points.  Bar: the path's 2e-5."""
+    import curl_oracle as O
+    r8, g8, b8 = torch.meshgrid(torch.arange(256), torch.arange(256), torch.arange(0, 256, 17), indexing="ij")
+    u8 = torch.stack((r8, g8, b8), -1).to(torch.uint8).reshape(1, 1024, 1024, 3).contiguous()
+    x = O.u8hwc_to_f32chw(u8[0].numpy())[None]
+    g = torch.Generator().manual_seed(3)
+    c = torch.randn(1, 3, 3, 126, generator=g) * 0.2
+    ref = O.generate_image(x, O.trispace_residual(x, c[:, 0], c[:, 1], c[:, 2]))
+    out = ops.trispace_forward(x.to(dev), c.to(dev))
+    err = float((out.cpu() - ref).abs().max())
+    print(f"8-bit cube slices, polynomial path: max |err| {err:.2e}")
+    assert err <= 2e-5
+    got = ops.trispace_forward_u8hwc(u8.to(dev), c.to(dev))
+    assert torch.equal(got, ops.f32chw_to_u8hwc(out))
+    want = _ref_bytes(ref.numpy())
+    diff = N(got) != want
+    assert np.abs(N(got).astype(int) - want.astype(int)).max() <= 1 and (~diff | _near_byte_boundary(ref.numpy(), 2e-5)).all()
