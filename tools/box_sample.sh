@@ -2,7 +2,7 @@
 # one data point of the box-to-box spread: the 3-plane copy probe and the headline workload on whatever box this call got
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/${TAG:-r04}; mkdir -p $O
 ID=$(cat /sys/class/drm/card*/device/unique_id 2>/dev/null | head -1)
 C=$(tools/ubench/copy3 2>/dev/null | grep "sustained tile T=256 U=2 nt=1" | head -1 | awk '{print $6}')
 python3 bench.py --no-extras --steps 1000 2>/dev/null | python3 -c "
