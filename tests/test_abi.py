@@ -80,6 +80,13 @@ def test_argument_errors_are_codes_not_crashes():
     assert lib.curl_hsv_stage_f32(fake, None, 1, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 0, None) == -5  # mask NULL
     assert lib.curl_hsv_stage_f32(fake, None, 0, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 0x2, None) == -6  # no PWL
     assert lib.curl_hsv_stage_f32(fake, None, 0, fake, fake, None, fake, 8, 1, 4, 4, 16, 0, None) == -4  # workspace
+    # round 4: the curve-collapse placement field takes 0, 1, 2; CURL_F_DIAG_SKIP_PREP belongs to the two layer-forward entries
+    assert lib.curl_layer_fwd_f32(fake, None, 0, fake, fake, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, 16, 16, 3 << 23,
+                                  None) == -6 and b"placement" in lib.curl_last_error()
+    assert lib.curl_lab_stage_f32(fake, None, 0, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, _lib.F_DIAG_SKIP_PREP, None) == -6
+    assert lib.curl_adjust_rgb_f32(fake, fake, fake, None, fake, 1 << 20, 1, 4, 4, 16, _lib.F_DIAG_SKIP_PREP, None) == -6
+    assert lib.curl_layer_bwd_f32(fake, None, 0, fake, fake, fake, fake, None, None, fake, fake, fake, fake, 1 << 20, fake, 1 << 20,
+                                  1, 4, 4, 16, 16, 16, _lib.F_DIAG_SKIP_PREP, None) == -6
     with pytest.raises(ValueError):
         _lib.check(-2, "x")
 
