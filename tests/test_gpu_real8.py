@@ -373,3 +373,38 @@ def test_polynomial_path_on_8bit_cube_slices(ops, dev):
     want = _ref_bytes(ref.numpy())
     diff = N(got) != want
     assert np.abs(N(got).astype(int) - want.astype(int)).max() <= 1 and (~diff | _near_byte_boundary(ref.numpy(), 2e-5)).all()
+
+
+def test_apply_curve_and_loss_terms_on_8bit_colours(ops, dev):
+    """Two more operators on exhaustive 8-bit input.  (1) curves.apply_curve in the reference's exact summation order, over the
+    whole colour cube: BIT-identical to the oracle (K = 16, three channel pairs; 4096 x 4096: a multiple of 32 pixels, the
+    shape class whose float32 reduction order ATen fixes).  (2) CURLLoss's pointwise terms (model.py:89-109: RGB L1, cosine, Lab
+    L1, HSV-cone L1 and the two L planes) on sixteen slices of the cube against a shuffled copy of themselves, bool mask:
+    every exact tie and every zero channel goes through the loss kernels' RGB2LAB / RGB2HSV too."""
+    import curl_oracle as O
+    n = 4096
+    idx = torch.arange(n * n, dtype=torch.int64)
+    x = (torch.stack((idx & 255, (idx >> 8) & 255, idx >> 16), 0).float() / 255.0).view(1, 3, n, n).contiguous()
+    g = torch.Generator().manual_seed(11)
+    C = torch.exp(torch.randn(1, 16, generator=g) * 0.3)
+    xd, Cd = x.to(dev), C.to(dev)
+    for ci, co in ((0, 0), (0, 1), (2, 2)):
+        got, _ = ops.apply_curve(xd, Cd, None, ci, co)                       # CURL_F_EXACT_ORDER: the default of this entry
+        want, _ = O.apply_curve(x, C, torch.zeros(1), ci, co)
+        assert torch.equal(got.cpu(), want), (ci, co)
+    del xd
+    r8, g8, b8 = torch.meshgrid(torch.arange(256), torch.arange(256), torch.arange(0, 256, 17), indexing="ij")
+    pred = (torch.stack((r8, g8, b8), 0).float() / 255).reshape(1, 3, 1024, 1024).contiguous()
+    perm = torch.randperm(1024 * 1024, generator=g)
+    target = pred.view(1, 3, -1)[:, :, perm].view(1, 3, 1024, 1024).contiguous()
+    mask = torch.rand(1, 1, 1024, 1024, generator=g) > 0.1
+    sums, Lp, Lt = ops.loss_term_sums(pred.to(dev), target.to(dev), mask.to(dev))
+    terms = O.curl_loss_terms(pred, target, mask)
+    got = sums.sum(0).cpu()
+    npx = 3.0 * float(got[4])
+    assert float(got[4]) == float(mask.sum())
+    for k, name in ((0, "rgb"), (2, "lab"), (3, "hsv")):
+        err = abs(float(got[k]) / npx - float(terms[k]))
+        print(f"8-bit cube slices, CURLLoss {name} term: |err| {err:.2e}")
+        assert err <= 3e-6, (name, err)
+    assert float((Lp.cpu() - terms[4]).abs().max()) <= 1e-6 and float((Lt.cpu() - terms[5]).abs().max()) <= 1e-6
