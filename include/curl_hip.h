@@ -101,7 +101,10 @@ enum {
 
 #define CURL_F_WS_READY 0x40000u /* curl_layer_bwd_f32: `workspace` is the buffer curl_layer_fwd_f32 (or an earlier backward) was
                                     handed for the SAME raw knots and has not been written since: it already holds the
-                                    exp'd knots and collapsed curves, the knot-prep launch is skipped */
+                                    exp'd knots and collapsed curves, the knot-prep launch is skipped.  Every prepared row
+                                    carries a stamp of the knot count and row stride it was filled for: a row nobody filled
+                                    for this call's shape (a zeroed buffer, another K) is answered with NaN knot gradients;
+                                    that the VALUES belong to these knots remains the caller's word */
 #define CURL_F_DIAG_SKIP_PREP 0x20000u /* DIAGNOSTICS ONLY (curl_layer_fwd_f32): the knot-prep launch is skipped and the
                                          workspace is taken to hold an earlier call's result for the same knots; `reg`
                                          is not written.  Measures what the prep launch + its kernel boundary cost. */
