@@ -94,6 +94,11 @@ WORKLOADS = {
     "layer_bwd_crop": dict(desc="curve-layer backward on the training crop batch, 32 x 256x256 (main.py:88, data.py:86), bool "
                                 "mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu", flop_px=412.5,
                            images=32, hw=(256, 256)),
+    "layer_bwd_knots": dict(desc="curve-layer backward, knot gradients only (grad_img = NULL: what the training step runs, the image "
+                                 "being data -- main.py:287): no RGB2LAB pullback, no gradient image written; 8 x 1500x1000 frames",
+                            bpp=25.0, frag="layer_bwd_kernel", mask="ones", bound="valu", flop_px=365.8, images=8, knots_only=True),
+    "layer_bwd_crop_knots": dict(desc="the same on the training crop batch, 32 x 256x256", bpp=25.0, frag="layer_bwd_kernel",
+                                 mask="ones", bound="valu", flop_px=365.8, images=32, hw=(256, 256), knots_only=True),
     "loss_fwd": dict(desc="CURLLoss pointwise terms forward (model.py:89-109: RGB L1, cosine, Lab L1, HSV-cone L1 of prediction "
                           "and target + the two L planes), bool mask all ones", bpp=33.0, frag="loss_terms_kernel",
                      mask="ones", bound="valu", flop_px=241.2),
@@ -103,7 +108,7 @@ WORKLOADS = {
                               "on 8 x 1500x1000 frames: three kernels, 72 B/px of intermediates between the first two",
                          bpp=24.0, frag="trispace_bwd", mask=None, bound="valu", flop_px=3120.0, images=8),
 }
-CONFIG5 = ("layer_bwd", "layer_bwd_crop", "loss_fwd", "loss_bwd", "trispace_bwd")
+CONFIG5 = ("layer_bwd", "layer_bwd_crop", "layer_bwd_knots", "layer_bwd_crop_knots", "loss_fwd", "loss_bwd", "trispace_bwd")
 
 
 def workload_pixels(name, B):
@@ -117,6 +122,7 @@ def make_step(name, ops, masks, sets=None):
     if name in CONFIG5:
         w = WORKLOADS[name]
         n = min(w.get("images", sets[0][0].shape[0]), sets[0][0].shape[0])
+        need_img = not w.get("knots_only", False)
         if "hw" in w:  # the training crop batch: its own small tensors
             h, wd = w["hw"]
             dev = sets[0][0].device
@@ -132,14 +138,15 @@ def make_step(name, ops, masks, sets=None):
                 k = turn[0] % len(crops)
                 c = crops[k]
                 turn[0] += 1
-                return ops.curl_layer_backward(c[0], m, c[1], c[2], c[3], gout, workspace=wss[k])
+                return ops.curl_layer_backward(c[0], m, c[1], c[2], c[3], gout, workspace=wss[k], need_grad_img=need_img)
             return crop_step
         gout = sets[1 % len(sets)][0][:n]  # any resident float image serves as the incoming gradient
         m = None if mask is None else mask[:n]
-        if name == "layer_bwd":
+        if name in ("layer_bwd", "layer_bwd_knots"):
             ws8 = [ops.curl_layer_forward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], return_workspace=True)[2] for s in sets]
             ids = {id(s): k for k, s in enumerate(sets)}
-            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gout, workspace=ws8[ids[id(s)]])
+            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gout, workspace=ws8[ids[id(s)]],
+                                                           need_grad_img=need_img)
         if name == "trispace_bwd":
             return lambda s: ops.trispace_backward(s[0][:n], s[4][:n], gout)
         other = sets[1 % len(sets)][0]

@@ -428,7 +428,10 @@ CURL_HD Px hsv2rgb_bwd(Px p, Px g) {
 // BINARY: m is exactly 0 or 1.  Where m == 1 the three intermediate `* mask` are the identity; where m == 0 the incoming
 // gradient gout * m is 0 and every factor on the tape is finite (the selects discard the branch not taken), so every
 // product on the way back is an exact 0: the intermediate multiplies go, as in the forward kernel.
-template <bool BINARY>
+// NEED_GIN = false: the caller wants the knot gradients only (training: the image is data, main.py:287) -- the chain stops
+// at the Lab curves' sums; RGB2LAB's pullback, its tape factors (two extra transcendentals per channel) and the residual
+// path's add are never computed.  P and Q are the same bits either way.
+template <bool BINARY, bool NEED_GIN = true>
 CURL_HD Px curl_layer_bwd(Px in, float m, const LayerCoef& k, Px gout, float* P, float* Q) {
   Rgb2LabT t_lab;
   Adjust3T t_al, t_ar;
@@ -457,7 +460,9 @@ CURL_HD Px curl_layer_bwd(Px in, float m, const LayerCoef& k, Px gout, float* P,
   if (!BINARY) g = Px{g.c0 * m, g.c1 * m, g.c2 * m};
   g = lab2rgb_pull(t_rgb, adjust3_pull(t_ar, g, P + 3, Q + 3));
   if (!BINARY) g = Px{g.c0 * m, g.c1 * m, g.c2 * m};
-  g = rgb2lab_pull(t_lab, adjust3_pull(t_al, g, P, Q));
+  g = adjust3_pull(t_al, g, P, Q);
+  if constexpr (!NEED_GIN) return g;  // (not d loss / d in: the caller ignores it)
+  g = rgb2lab_pull(t_lab, g);
   return Px{g.c0 + g_pre.c0, g.c1 + g_pre.c1, g.c2 + g_pre.c2};
 }
 

@@ -24,6 +24,7 @@ KERNELS = {
     "layer": ["OpLayer"], "layer_8bit": ["OpLayer"], "lab_stage": ["OpLabStage"], "hsv_stage": ["OpHsvStage"],
     "rgb_only": ["OpAdjust3"], "trispace": ["OpTriSpace"],
     "layer_bwd": ["layer_bwd_kernel", "knots_bwd_kernel"], "layer_bwd_crop": ["layer_bwd_kernel", "knots_bwd_kernel"],
+    "layer_bwd_knots": ["layer_bwd_kernel", "knots_bwd_kernel"], "layer_bwd_crop_knots": ["layer_bwd_kernel", "knots_bwd_kernel"],
     "loss_fwd": ["loss_terms_kernel", "loss_terms_final_kernel"], "loss_bwd": ["loss_terms_bwd_kernel"],
     "trispace_bwd": ["trispace_bwd_px", "trispace_coef_grad", "trispace_coef_final", "trispace_bwd_fused"],
 }

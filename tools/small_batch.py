@@ -103,8 +103,17 @@ for (B, H, W) in ((1, 1000, 1500), (2, 1000, 1500), (4, 1000, 1500), (32, 256, 2
                                     scratch.data_ptr(), sb, B, H, W, 16, 16, 16, _lib.F_WS_READY | args.flags_bwd, stream)
         assert rc == 0, lib.curl_last_error()
 
+    def bwdk_py():  # knot gradients only: what autograd asks for when the image needs no gradient (the training step)
+        return ops.curl_layer_backward(img(), mask, L, R, Hk, gout, workspace=ws_py, flags=args.flags_bwd, need_grad_img=False)
+
+    def bwdk_c():
+        rc = lib.curl_layer_bwd_f32(img().data_ptr(), m8.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(), gout.data_ptr(), 0,
+                                    0, gL.data_ptr(), gR.data_ptr(), gH.data_ptr(), ws.data_ptr(), nbytes,
+                                    scratch.data_ptr(), sb, B, H, W, 16, 16, 16, _lib.F_WS_READY | args.flags_bwd, stream)
+        assert rc == 0, lib.curl_last_error()
+
     n = args.n if B * H * W < 16e6 else 100
-    for name, py, c in (("fwd", fwd_py, fwd_c), ("bwd", bwd_py, bwd_c)):
+    for name, py, c in (("fwd", fwd_py, fwd_c), ("bwd", bwd_py, bwd_c), ("bwdk", bwdk_py, bwdk_c)):
         w, h = window(py, n)
         wc, hc = window(c, n)
         lat = latency(c)
