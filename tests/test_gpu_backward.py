@@ -60,8 +60,8 @@ def test_knot_gradients_alone_agree_with_the_full_backward(ops, dev, shape):
     """grad_img = NULL (the training step: the image is data, main.py:287) picks the kernel instantiation without RGB2LAB's
     pullback and without the gradient image's stores.  The knot gradients are the same arithmetic, but NOT guaranteed the
     same bits: hipcc contracts a*b+c into an fma depending on how many uses the product has, and the dead pullback changes
-    the use counts (measured: of 40 gradient tensors x 5 shapes x 3 masks ONE sum differed, by one ulp -- 1.5e-5 of 210,
-    tools/scratch history in profiles/r04/SUMMARY.md).  Asserted: each gradient tensor within 1e-6 of its largest entry
+    the use counts (measured over these five shapes x three masks x with / without the workspace: 88 of 90 gradient tensors
+    the same bits, two with one sum one ulp off -- 1.5e-5 of 210).  Asserted: each gradient tensor within 1e-6 of its largest entry
     (the float64-pinned bound of test_backward_parity_is_pinned_to_float64_autograd, which both variants meet, is 2e-5)."""
     B, H, W = shape
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + H)
