@@ -167,6 +167,10 @@ struct Rgb2LabT {
   float df3[3];   // 3 d f / d t_r  (t^(-2/3), or 3 / (3 eps^2) on the linear branch)
 };
 CURL_HD Px rgb2lab_t(Px p, Rgb2LabT& t) {
+  // No implicit a*b+c contraction in here (the explicit fmaf's stay): hipcc's default contracts across statements depending on
+  // how many uses a product has, so the SAME source gave different bits in different callers -- and CURLLoss's backward needs
+  // this function to map equal colours to equal values (curl_math_loss.h: sign(lp - lt) must be 0 where pred == target).
+#pragma clang fp contract(off)
   const float x[3] = {p.c0, p.c1, p.c2};
   float u[3], e[3], lin[3];
   for (int c = 0; c < 3; ++c) u[c] = fmaf(x[c], kInv1055, (float)(0.055 / 1.055));
@@ -198,7 +202,10 @@ CURL_HD Px rgb2lab_t(Px p, Rgb2LabT& t) {
     t.df3[r] = lm_sel(lo, k_df, t.df3[r]);
   }
   Px o;
-  o.c0 = fmaf(f[1], 1.16f, -0.16f);
+  // L = 1.16 fy - 0.16 as 1.16 (fy - 4/29): EXACTLY 0 at black (fy = 4/29), where the reference's float32 (116 * fy rounds to
+  // 16.0, colors.py:50-56) and float64 evaluations both give L >= 0 and torch.clamp's gate at 0 passes the gradient; the single
+  // fma gave -1.6e-9 there and closed it on every black pixel of a photograph (tests: photograph_dark, the black colour)
+  o.c0 = (f[1] - k4_29) * 1.16f;
   o.c1 = fmaf(f[0] - f[1], (float)(500.0 / 220.0), 0.5f);
   o.c2 = fmaf(f[1] - f[2], (float)(200.0 / 220.0), 0.5f);
   return o;
@@ -274,6 +281,7 @@ struct Rgb2HsvT {
   float df, dfi, mxi, Nn;  // max - min, 1 / (max - min) (0 where flat), 1 / max, the selected hue numerator
 };
 CURL_HD Px rgb2hsv_t(Px p, Rgb2HsvT& t) {
+#pragma clang fp contract(off)  // (as rgb2lab_t)
   const float r = clamp_gate(p.c0, kHsvFloor, 1.0f, t.pin[0]), g = clamp_gate(p.c1, kHsvFloor, 1.0f, t.pin[1]),
               b = clamp_gate(p.c2, kHsvFloor, 1.0f, t.pin[2]);
   const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));

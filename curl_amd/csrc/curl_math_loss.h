@@ -41,6 +41,7 @@ CURL_HD void cos_sin_turns(float h, float& c, float& s) {
 }
 
 CURL_HD Px hsv_cone(Px hsv) {  // model.py:65-76 on clamp(rgb2hsv(x), 0, 1)
+#pragma clang fp contract(off)  // (equal colours -> equal cones, whatever the caller does with them: loss_terms_bwd)
   float h = clamp01(hsv.c0), s = clamp01(hsv.c1), v = clamp01(hsv.c2);
   float ca, sa;
   cos_sin_turns(h, ca, sa);
@@ -136,35 +137,47 @@ CURL_HD float sign0(float x) {
 
 // d(sum_k w[k] * term_k + gLp * Lp) / d pred for one pixel; w = weights of (rgb_l1, cos_sim, lab_l1, hsv_l1).
 CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float gLp) {
+  // The differences below feed torch.sign: contracted into fma(v s, cos, -cone_t) -- exact product minus rounded product -- a
+  // difference of EQUAL cones is a rounding residue and its sign +-1, where the reference has sign(0) = 0 (found in round 4 with
+  // pred == target pixels; the host twin is built without contraction and never saw it).  Explicit fmaf's only in here.
+#pragma clang fp contract(off)
   Px p{pred.c0 * m, pred.c1 * m, pred.c2 * m}, t{tgt.c0 * m, tgt.c1 * m, tgt.c2 * m};
   // rgb L1
   Px g{w[0] * sign0(p.c0 - t.c0), w[0] * sign0(p.c1 - t.c1), w[0] * sign0(p.c2 - t.c2)};
   // cosine similarity: c = d / (max(np,eps) max(nt,eps))
-  float d = p.c0 * t.c0 + p.c1 * t.c1 + p.c2 * t.c2;
-  float np = loss_sqrt(p.c0 * p.c0 + p.c1 * p.c1 + p.c2 * p.c2), nt = loss_sqrt(t.c0 * t.c0 + t.c1 * t.c1 + t.c2 * t.c2);
+  float d = fmaf(p.c2, t.c2, fmaf(p.c1, t.c1, p.c0 * t.c0));
+  float np = loss_sqrt(fmaf(p.c2, p.c2, fmaf(p.c1, p.c1, p.c0 * p.c0))), nt = loss_sqrt(fmaf(t.c2, t.c2, fmaf(t.c1, t.c1, t.c0 * t.c0)));
   float npc = fmaxf(np, kCosEps), ntc = fmaxf(nt, kCosEps);
   float inv = hw_rcp(npc * ntc);
   // d/dp of 1/max(np,eps) is -p/np^3-ish only when np > eps (sign-bit mask of eps - np; np = 0 gives 0 * inf masked to 0)
   float k = keep_if(neg_mask(kCosEps - np), d * inv * hw_rcp(npc * fmaxf(np, kCosEps)));
-  g.c0 += w[1] * (t.c0 * inv - k * p.c0);
-  g.c1 += w[1] * (t.c1 * inv - k * p.c1);
-  g.c2 += w[1] * (t.c2 * inv - k * p.c2);
+  g.c0 = fmaf(w[1], fmaf(-k, p.c0, t.c0 * inv), g.c0);
+  g.c1 = fmaf(w[1], fmaf(-k, p.c1, t.c1 * inv), g.c1);
+  g.c2 = fmaf(w[1], fmaf(-k, p.c2, t.c2 * inv), g.c2);
   // Lab L1 (+ the MS-SSIM gradient arriving on the clamped L plane)
-  Px lp = rgb2lab(p), lt = rgb2lab(t);
+  // (the prediction's Lab from the TAPED converter: its L is exactly 0 at black -- a prediction the layer's clamp saturated at 0 --
+  // where the reference's is, so model.py:55's clamp gate passes there as torch's does; curl_math_bwd.h rgb2lab_t)
+  // The target goes through the same function (its tape is dead code): pred == target must give lp == lt bit for bit, as in
+  // the reference, or sign(lp - lt) would be +-1 where torch.sign(0) is 0.
+  Rgb2LabT tape_lab, tape_unused;
+  Px lp = rgb2lab_t(p, tape_lab), lt = rgb2lab_t(t, tape_unused);
   Px lpc{clamp01(lp.c0), clamp01(lp.c1), clamp01(lp.c2)}, ltc{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
-  Px gl{(w[2] * sign0(lpc.c0 - ltc.c0) + gLp) * pass01(lp.c0), w[2] * sign0(lpc.c1 - ltc.c1) * pass01(lp.c1),
+  Px gl{fmaf(w[2], sign0(lpc.c0 - ltc.c0), gLp) * pass01(lp.c0), w[2] * sign0(lpc.c1 - ltc.c1) * pass01(lp.c1),
         w[2] * sign0(lpc.c2 - ltc.c2) * pass01(lp.c2)};
-  Px g_lab = rgb2lab_bwd(p, gl);
+  Px g_lab = rgb2lab_pull(tape_lab, gl);
   // HSV cone L1
-  Px hp = rgb2hsv(p);
-  Px cp = hsv_cone(hp), ct = hsv_cone(rgb2hsv(t));
+  // (the taped converter for both colours, as for Lab: one evaluation of the prediction's forward instead of rgb2hsv +
+  // rgb2hsv_bwd's own, and pred == target gives identical cones)
+  Rgb2HsvT tape_hsv, tape_hsv_unused;
+  Px hp = rgb2hsv_t(p, tape_hsv);
+  Px cp = hsv_cone(hp), ct = hsv_cone(rgb2hsv_t(t, tape_hsv_unused));
   float ge0 = w[3] * sign0(cp.c0 - ct.c0), ge1 = w[3] * sign0(cp.c1 - ct.c1), ge2 = w[3] * sign0(cp.c2 - ct.c2);
   float h = clamp01(hp.c0), s = clamp01(hp.c1), v = clamp01(hp.c2);
   float ca, sa;
   cos_sin_turns(h, ca, sa);
-  Px gh{kTwoPi * v * s * (ge1 * ca - ge0 * sa) * pass01(hp.c0), v * (ge0 * ca + ge1 * sa) * pass01(hp.c1),
-        (s * (ge0 * ca + ge1 * sa) + ge2) * pass01(hp.c2)};
-  Px g_hsv = rgb2hsv_bwd(p, gh);
+  const float radial = fmaf(ge1, sa, ge0 * ca);
+  Px gh{kTwoPi * v * s * fmaf(ge1, ca, -(ge0 * sa)) * pass01(hp.c0), v * radial * pass01(hp.c1), fmaf(s, radial, ge2) * pass01(hp.c2)};
+  Px g_hsv = rgb2hsv_pull(tape_hsv, gh);
   return Px{(g.c0 + g_lab.c0 + g_hsv.c0) * m, (g.c1 + g_lab.c1 + g_hsv.c1) * m, (g.c2 + g_lab.c2 + g_hsv.c2) * m};
 }
 

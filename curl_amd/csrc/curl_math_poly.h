@@ -360,15 +360,19 @@ CURL_HD void trispace_bwd_n(const PxN<N>& in, const float (&xw)[N], const float 
   for (int i = 0; i < N; ++i) {  // reverse mode through the converters, one pixel at a time
     Px s1{sig[1][0][i], sig[1][1][i], sig[1][2][i]}, s2{sig[2][0][i], sig[2][1][i], sig[2][2][i]};
     Px g_res{gout.c0[i], gout.c1[i], gout.c2[i]};
+    // the taped converters: their forward values serve generate_image's clamp gate, their tapes the pullbacks (one evaluation
+    // each; until round 4 lab2rgb / hsv2rgb ran here and again inside lab2rgb_bwd / hsv2rgb_bwd)
+    Lab2RgbT t1;
+    Hsv2RgbT t2;
+    const Px y1 = lab2rgb_t(s1, t1), y2 = hsv2rgb_t<false>(s2, t2);
     if (!residual_only) {  // generate_image: clamp(img + residual, 0, 1)
-      Px y1 = lab2rgb(s1), y2 = hsv2rgb(s2);
       float r0 = 2.0f * (sig[0][0][i] - 0.5f) + 2.0f * (y1.c0 - 0.5f) + 2.0f * (y2.c0 - 0.5f);
       float r1 = 2.0f * (sig[0][1][i] - 0.5f) + 2.0f * (y1.c1 - 0.5f) + 2.0f * (y2.c1 - 0.5f);
       float r2 = 2.0f * (sig[0][2][i] - 0.5f) + 2.0f * (y1.c2 - 0.5f) + 2.0f * (y2.c2 - 0.5f);
       g_res = Px{g_res.c0 * pass01(in.c0[i] + r0), g_res.c1 * pass01(in.c1[i] + r1), g_res.c2 * pass01(in.c2[i] + r2)};
     }
     Px gy{2.0f * g_res.c0, 2.0f * g_res.c1, 2.0f * g_res.c2};
-    Px gs[3] = {gy, lab2rgb_bwd(s1, gy), hsv2rgb_bwd(s2, gy)};
+    Px gs[3] = {gy, lab2rgb_pull(t1, gy), hsv2rgb_pull<false>(t2, gy)};
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       gP[s][0][i] = gs[s].c0 * sig[s][0][i] * (1.0f - sig[s][0][i]);

@@ -54,6 +54,47 @@ def test_twin_backward(twin, golden):
     assert np.quantile(d, 0.995) <= 2e-4 * scale and d.max() <= 5e-2 * scale
 
 
+def equal_and_black_case():
+    """Pixel pairs a training step is full of and random floats never produce: prediction == target bit for bit (saturated
+    highlights, black, a copied mid-tone), a BLACK prediction (the layer's clamp at 0) against a dark target, and the reverse."""
+    g = torch.Generator().manual_seed(9)
+    same = torch.tensor([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0.25, 0.5, 0.75], [1, 0, 0], [0.2, 0.2, 0.9]]).t()
+    rnd = torch.rand(3, 10, generator=g)
+    pred = torch.cat([same, rnd, torch.zeros(3, 8), torch.rand(3, 8, generator=g) * 0.1, torch.rand(3, 8, generator=g)], 1)
+    tgt = torch.cat([same, rnd, torch.rand(3, 8, generator=g) * 0.1, torch.zeros(3, 8), torch.rand(3, 8, generator=g)], 1)
+    n = pred.shape[1]
+    return pred.reshape(1, 3, 1, n).contiguous(), tgt.reshape(1, 3, 1, n).contiguous(), torch.ones(1, 1, 1, n), len(same.t()) + 10
+
+
+def oracle_loss_gradient(pred, tgt, mask, w, dtype):
+    p = pred.detach().clone().to(dtype).requires_grad_(True)
+    rgb, cosine, lab, hsv, _, _ = O.curl_loss_terms(p, tgt.to(dtype), mask.to(dtype))
+    (w[0] * rgb + w[1] * cosine + w[2] * lab + w[3] * hsv).backward()
+    return p.grad
+
+
+def test_twin_backward_where_prediction_equals_target_and_at_black(twin):
+    """torch.sign(0) = 0: where prediction and target are the same bits every L1 term's gradient vanishes, so the two colours
+    must go through the same arithmetic (one converter for both; round 4 found the taped and the plain RGB2LAB an ulp apart).
+    A black prediction: the clamp gate of model.py:55 on an L of exactly 0 passes the gradient in the reference."""
+    pred, tgt, mask, n_same = equal_and_black_case()
+    # (the cosine term is off here: at a black prediction its reference gradient is target / (1e-8 |target|) ~ 1e6 and would
+    # be the whole scale; it has no gate at black and is covered by test_twin_backward)
+    w = (1.3, 0.0, 2.0, 0.5)
+    n = pred.shape[-1]
+    for m in (mask, torch.full_like(mask, 0.37)):
+        unmasked = 3.0 * float(m.sum())
+        w4 = np.array([w[0] / unmasked, -w[1] / n, w[2] / unmasked, w[3] / unmasked], np.float32)
+        g64 = oracle_loss_gradient(pred, tgt, m, w, torch.float64).numpy()
+        g32 = oracle_loss_gradient(pred, tgt, m, w, torch.float32).numpy()
+        got = twin.loss_terms_bwd(pred.numpy(), tgt.numpy(), m.numpy(), w4, None)
+        scale = np.abs(g64).max()
+        assert np.abs(g32 - g64).max() <= 1e-5 * scale, "the reference's float32 gradient is unambiguous here"
+        d = np.abs(got - g64)[0, :, 0]
+        assert d.max() <= 1e-5 * scale, (int(d.max(0).argmax()), float(d.max()), float(scale))
+        assert np.abs(got[0, :, 0, :n_same]).max() <= 1e-6 * scale   # identical pixels: nothing is left
+
+
 @pytest.mark.parametrize("tag", ["loss", "rgb", "w5"])
 def test_msssim_host_mirror_vs_reference_golden(golden, tag):
     """curl_amd.metric.MSSSIMMetric (stock torch, separable window, no .cuda()) against outputs and gradients of

@@ -67,6 +67,42 @@ def test_vs_oracle_autograd(twin, case):
             assert rel(a, b) <= 1e-3, (case, name, rel(a, b))
 
 
+STRUCTURED_COLOURS = np.array([[0, 0, 0], [1, 1, 1], [0, 0, 1], [1, 0, 0], [0, 1, 0], [2, 2, 2], [10, 10, 10], [128, 128, 128],
+                               [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255],
+                               [0, 0, 128], [128, 0, 0], [0, 128, 0], [10, 10, 0], [0, 10, 10]], np.float32) / 255
+
+
+def structured_case(seed, shift):
+    n = len(STRUCTURED_COLOURS)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.from_numpy(STRUCTURED_COLOURS.T.reshape(1, 3, 1, n).copy())
+    mask = torch.ones(1, 1, 1, n)
+    L, R, Hk = (torch.randn(1, k, generator=g) * 0.1 + shift for k in (48, 48, 64))
+    w = torch.randn(1, 3, 1, n, generator=g)
+    wr = torch.rand(1, generator=g)
+    return img, mask, L, R, Hk, w, wr
+
+
+@pytest.mark.parametrize("shift", [-0.7, -0.3, 0.0])
+def test_black_and_the_corners_of_the_colour_cube(twin, shift):
+    """Colours every photograph is full of and random floats never hit: BLACK, near-black, greys, white, the primaries and
+    secondaries, single dark channels.  At black the reference's L is exactly 0 in float32 (116 * float32(4/29) rounds to 16.0,
+    colors.py:50-56) and >= 0 in float64, and torch.clamp's gate at 0 passes the gradient on; an L of -1.6e-9 -- the single-fma
+    form 1.16 fy - 0.16 the backward had until round 4 -- closed it on all 2 194 black pixels of the `dark` photograph, and
+    the exception set of the float64-pinned GPU test (a gradient jump within 1e-6 of the input: it IS one) hid that.  Here
+    nothing is excused: every colour within 5e-6 of the gradient scale of the float64 gradient, as the reference's own float32
+    autograd is."""
+    for seed in (3, 4, 5):
+        img, mask, L, R, Hk, w, wr = structured_case(seed, shift)
+        g64 = O.layer_gradients(img, mask, L, R, Hk, w, wr)[0].numpy()
+        g32 = O.layer_gradients(img, mask, L, R, Hk, w, wr, dtype=torch.float32)[0].numpy()
+        got = twin.layer_bwd(img.numpy(), mask.numpy(), L.numpy(), R.numpy(), Hk.numpy(), w.numpy(), wr.numpy())[0]
+        tol = 5e-6 * max(1.0, float(np.abs(g64).max()))
+        assert np.abs(g32 - g64).max() <= tol, "the reference's own float32 gradient is unambiguous on these colours"
+        d = np.abs(got - g64)[0, :, 0]
+        assert d.max() <= tol, (shift, seed, (STRUCTURED_COLOURS[d.max(0).argmax()] * 255).tolist(), float(d.max()))
+
+
 def test_regulariser_gradient_only(twin):
     """gout = 0: the knot gradient is the regulariser's alone (curves.py:19,24 through exp)."""
     g = torch.Generator().manual_seed(5)
