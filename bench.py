@@ -103,10 +103,10 @@ WORKLOADS = {
                           "and target + the two L planes), bool mask all ones", bpp=33.0, frag="loss_terms_kernel",
                      mask="ones", bound="valu", flop_px=241.2),
     "loss_bwd": dict(desc="CURLLoss pointwise terms backward (gradient w.r.t. the prediction)", bpp=41.0,
-                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=415.0),
+                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=362.0),
     "trispace_bwd": dict(desc="polynomial path backward (curl_trispace_bwd_f32: d loss / d 3x3x126 coefficients, main.py:287) "
                               "on 8 x 1500x1000 frames: three kernels, 72 B/px of intermediates between the first two",
-                         bpp=24.0, frag="trispace_bwd", mask=None, bound="valu", flop_px=3120.0, images=8),
+                         bpp=24.0, frag="trispace_bwd", mask=None, bound="valu", flop_px=3059.0, images=8),
 }
 CONFIG5 = ("layer_bwd", "layer_bwd_crop", "layer_bwd_knots", "layer_bwd_crop_knots", "loss_fwd", "loss_bwd", "trispace_bwd")
 
