@@ -488,7 +488,11 @@ class _LossTermsFn(torch.autograd.Function):
         n = float(pred.shape[0] * pred.shape[2] * pred.shape[3])
         unmasked = 3.0 * s[4]
         rgb, lab, hsv = s[0] / unmasked, s[2] / unmasked, s[3] / unmasked
-        cosine = 1.0 - s[1] / n - (n - s[4]) / n  # model.py:98: mean over the broadcast [B,B,H,W]
+        # model.py:98 adds torch.logical_not(mask) -- 1 where the mask is EXACTLY 0 -- and takes the mean over the broadcast
+        # [B,B,H,W].  bool / uint8 masks (data.py:190): their zeros are n - sum; a float mask with values strictly inside
+        # (0, 1) has none of those counted, so its zeros are counted as such.
+        n_zero = (mask == 0).sum().double() if (mask is not None and mask.is_floating_point()) else n - s[4]
+        cosine = 1.0 - s[1] / n - n_zero / n
         ctx.save_for_backward(pred, target, unmasked)
         ctx.mask, ctx.n = mask, n
         ctx.mark_non_differentiable(Lt)

@@ -355,6 +355,26 @@ def test_curl_loss_module_vs_oracle(dev):
     assert float(torch.quantile(d.flatten(), 0.995)) <= 2e-4 * float(pc.grad.abs().max())
 
 
+def test_curl_loss_float_mask_strictly_inside_the_unit_interval(dev):
+    """model.py:98's torch.logical_not(mask) counts the pixels whose mask is EXACTLY 0; under a float mask with fractional
+    values that is not n - mask.sum() (round 4: the cosine term was off by the mask's mean)."""
+    import curl_oracle as O
+    from curl_amd import model
+    g = torch.Generator().manual_seed(18)
+    pred, tgt = torch.rand(2, 3, 40, 56, generator=g), torch.rand(2, 3, 40, 56, generator=g)
+    soft = torch.rand(2, 1, 40, 56, generator=g) * 0.8 + 0.1
+    soft[:, :, :5] = 0.0  # ... and some exact zeros
+    p = pred.to(dev).requires_grad_(True)
+    got = model.CURLLoss(msssim_layer=None)(p, tgt.to(dev), soft.to(dev))
+    got.backward()
+    pc = pred.clone().double().requires_grad_(True)
+    want = O.curl_loss(pc, tgt.double(), soft.double(), torch.tensor(0.0, dtype=torch.float64))
+    want.backward()
+    assert abs(float(got) - float(want)) <= 2e-6, (float(got), float(want))
+    d = (p.grad.cpu().double() - pc.grad).abs()
+    assert float(torch.quantile(d.flatten(), 0.995)) <= 2e-4 * float(pc.grad.abs().max())
+
+
 def test_curl_loss_with_msssim_vs_oracle(dev):
     """The module as the reference builds it (model.py:48: MS-SSIM of the clamped L planes, window 11), value and
     gradient against the oracle's restatement (pinned by the reference's own class, golden msssim.npz)."""

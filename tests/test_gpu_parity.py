@@ -587,6 +587,35 @@ def test_psnr_golden_and_oracle(dev, golden):
     assert metric.PSNRMetric()(a, b, empty) is None  # 0/0 -> NaN for every image -> None (metric.py:67-68)
 
 
+def test_psnr_special_cases_vs_oracle(dev):
+    """What an evaluation run meets and random floats do not (metric.py:35-68): identical images (zero error: +inf, which
+    nanmean keeps), an image whose mask is empty beside live ones (0/0 = NaN, which nanmean skips), a float mask with
+    fractional values (the reference multiplies by it and divides by 3 * its sum), inputs outside [0, 1] (clamped first)."""
+    import math
+    import curl_oracle as O
+    from curl_amd import metric, ops as _ops
+    g = torch.Generator().manual_seed(31)
+    a = torch.rand(3, 3, 33, 47, generator=g) * 1.4 - 0.2
+    b = torch.rand(3, 3, 33, 47, generator=g) * 1.4 - 0.2
+    b[1] = a[1]                                   # image 1: identical
+    ones = torch.ones(3, 1, 33, 47)
+    soft = torch.rand(3, 1, 33, 47, generator=g) * 0.9 + 0.05
+    hole = ones.clone()
+    hole[2] = 0.0                                 # image 2: nothing unmasked
+    for m in (ones, ones.bool(), soft, hole, hole.bool()):
+        per = _ops.psnr_per_image(a.to(dev), b.to(dev), m.to(dev)).cpu()
+        for i in range(3):
+            want = O.psnr(a[i:i + 1], b[i:i + 1], m[i:i + 1].float())
+            if want is None:
+                assert math.isnan(float(per[i])), (i, float(per[i]))
+            elif math.isinf(float(want)):
+                assert float(per[i]) == float(want)
+            else:
+                assert abs(float(per[i]) - float(want)) < 1e-4, (i, float(per[i]), float(want))
+        got, ref = metric.PSNRMetric()(a.to(dev), b.to(dev), m.to(dev)), O.psnr(a, b, m.float())
+        assert (got is None) == (ref is None) and (ref is None or float(got) == float(ref) or abs(float(got) - float(ref)) < 1e-4)
+
+
 def test_hip_graph_capture_and_replay(ops, dev, golden):
     """The C ABI never allocates or synchronises, so a whole step (knot prep + fused layer) captures into a
     hipGraph and replays on new data in the same buffers."""
