@@ -213,7 +213,7 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     # contribution (on the cube slices: (79, 238, 34) alone moves d L by 1e-2 of its scale; on the full-size frame the
     # reference's OWN float32 autograd flips one of the 17).  The statement that does not depend on which side of a kink a
     # rounding falls: with the exception set masked out of both evaluations, the knot gradients agree to tol_knots.
-    mask_ex, want_knots = mask, (gL64, gR64, gH64)
+    mask_ex, want_knots, g32 = mask, (gL64, gR64, gH64), None
     if bool(jump.any()):
         mask_ex = mask & ~jump[:, None]
         want_knots = O.layer_gradients(img, mask_ex.float(), L, R, Hk, w, wr)[1:]
@@ -245,6 +245,17 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
         else:
             assert int(jump.sum()) <= 1e-3 * jump.numel()
         assert float(d[jump].max() if bool(jump.any()) else 0.0) <= 2.0 * G    # even there: a gate flipped, nothing worse
+        # The exception set excuses a pixel only while the REFERENCE is of two minds about it.  Where its float32 and its
+        # float64 autograd agree (the gate is not a coin toss of its arithmetic: black is the example, L is exactly 0 there) a
+        # gate-sized error of the kernel is a flip of its own; a true knife edge may produce one now and then (the cube slices:
+        # (79, 238, 34)), a systematic one produces thousands (the `dark` photograph's 2 169 black pixels, round 4).
+        if bool(jump.any()):
+            if g32 is None:
+                g32 = O.layer_gradients(img, mf, L, R, Hk, w, wr, dtype=torch.float32)[0].double()
+            unambiguous = (g32 - g64).abs().amax(1) <= 1e-4 * G
+            lone = (d > 1e-3 * G) & unambiguous
+            print(f"   exception pixels where the reference's float32 and float64 agree and the kernel alone is off: {int(lone.sum())}")
+            assert int(lone.sum()) <= max(3, int(1e-5 * lone.numel())), int(lone.sum())
         assert (gi.cpu()[:, :, ~mask[0, 0]] == 0).all() if case == "coherent_8bit_dim_knots" else True
 
 
