@@ -48,6 +48,7 @@ def main():
     cnt = [0]
     gout = torch.rand(B, 3, H, W, device=dev) if what == "layer_bwd" else None
     gin = torch.empty_like(out)
+    no_gin = bool(os.environ.get("NO_GIN"))  # layer_bwd: grad_img = NULL, the knots-only kernel
     gL, gR, gH = torch.empty_like(L), torch.empty_like(R), torch.empty_like(Hk)
     sb = libs["A"].curl_layer_bwd_scratch_bytes(B, H, W)
     scratch = torch.empty(max(4, sb) // 4, device=dev)
@@ -71,7 +72,7 @@ def main():
                                         out.data_ptr(), reg.data_ptr(), ws.data_ptr(), nb, B, H, W, 16, 16, 16, flags, stream)
         elif what == "layer_bwd":
             rc = lib.curl_layer_bwd_f32(img.data_ptr(), mask.data_ptr(), 1, L.data_ptr(), R.data_ptr(), Hk.data_ptr(),
-                                        gout.data_ptr(), 0, gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
+                                        gout.data_ptr(), 0, 0 if no_gin else gin.data_ptr(), gL.data_ptr(), gR.data_ptr(), gH.data_ptr(),
                                         ws.data_ptr(), nb, scratch.data_ptr(), sb, B, H, W, 16, 16, 16, flags & 0x400000, stream)
         elif what == "loss_fwd":
             rc = lib.curl_loss_terms_f32(img.data_ptr(), imgs[1 - (cnt[0] & 1)].data_ptr(), mask.data_ptr(), 1, loss_sums.data_ptr(),
