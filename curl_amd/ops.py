@@ -155,7 +155,10 @@ def _knots(t, name, ncurves, B):
 
 
 def _mask(mask, img):
-    """-> (tensor or None, mask_kind).  Accepts None, bool/uint8 or floating [B|1,1,H,W]."""
+    """-> (tensor or None, mask_kind).  Accepts None, bool/uint8 or floating [B|1,1,H,W].
+    bool is what the reference passes (data.py:190: `mask > 0`).  A uint8 mask is read the same way -- NONZERO KEEPS the pixel --
+    which equals torch's `img * mask` for bytes 0 / 1 only: a 0 / 255 mask straight from a PNG would scale by 255 in torch.
+    A floating mask multiplies by its value, as torch does (pass `mask.float()` for that behaviour with other integer types)."""
     if mask is None:
         return None, MASK_NONE
     _need_device(mask, "mask")
