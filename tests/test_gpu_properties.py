@@ -8,7 +8,7 @@ from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
 import curl_oracle as O
-from test_properties import channel, pixels, unit_channel, _near
+from test_properties import channel, layer_backward_lone_flips, pixels, unit_channel, _near
 
 import os
 
@@ -102,3 +102,24 @@ def test_fused_hsv_stage_kernel_error_is_bounded_by_its_conditioning(ops, x, see
     d = (got.cpu().double() - ref.double()).abs().amax(1)
     bound = torch.clamp(2e-6 * S, min=3e-6)
     assert bool((d <= bound).all()), (float(d.max()), float(S.max()))
+
+
+def _pad(t, n=256):
+    """[1,C,1,P] -> [1,C,1,n] by repeating the pixels (a launch of a few pixels and one of a wavefront's worth run the same code;
+    the float4 path needs a multiple of four)."""
+    reps = -(-n // t.shape[3])
+    return t.repeat(1, 1, 1, reps)[..., :n].contiguous()
+
+
+@settings(max_examples=int(60 * SCALE), **COMMON)
+@given(x=pixels(elem=unit_channel, max_px=8), seed=st.integers(0, 2 ** 16), kind=st.sampled_from(["none", "bool", "f32"]),
+       shift=st.sampled_from([-0.7, -0.3, 0.0]))
+def test_layer_backward_kernel_where_the_reference_is_unambiguous(ops, x, seed, kind, shift):
+    """tests/test_properties.py's statement on the device (curl_layer_bwd_f32, every mask kind): wherever the reference's
+    float32 and float64 autograd agree on a pixel's gradient, the kernel may not be off by a gate."""
+    def backward(img, ones, L, R, H, w, wr):
+        P = img.shape[3]
+        mask = None if kind == "none" else (_pad(ones).bool().cuda() if kind == "bool" else _pad(ones).cuda())
+        return ops.curl_layer_backward(_pad(img).cuda(), mask, L.cuda(), R.cuda(), H.cuda(), _pad(w).cuda(), wr.cuda())[0].cpu()[..., :P]
+    bad, dmax, Gs = layer_backward_lone_flips(backward, x, seed, shift)
+    assert not bad, (bad, dmax, Gs)
