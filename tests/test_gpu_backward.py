@@ -431,6 +431,27 @@ def test_trispace_backward_vs_oracle_autograd(ops, dev, nc, residual_only, shape
     assert torch.equal(got, again)  # fixed-order reduction: bit-reproducible
 
 
+@pytest.mark.parametrize("residual_only", [False, True])
+def test_trispace_backward_on_8bit_content(ops, dev, residual_only):
+    """tests/test_poly.py's statement on the device: the polynomial path's coefficient gradient on a whole photograph of the
+    reference (bytes / 255: exact ties, the pixels generate_image's clamp pins) with black, white, grey and primary pixels
+    written into it, against autograd through the oracle in FLOAT64."""
+    import curl_oracle as O
+    real = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real8.npz"))
+    u8 = real["crop_u8"].copy()
+    u8[0, :6] = [[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255]]
+    img = O.u8hwc_to_f32chw(u8)[None].repeat(2, 1, 1, 1)
+    g = torch.Generator().manual_seed(5 + residual_only)
+    coeffs = torch.randn(2, 3, 3, 126, generator=g) * 0.3
+    w = torch.randn(2, 3, 256, 256, generator=g)
+    c64 = coeffs.double().requires_grad_(True)
+    res = O.trispace_residual(img.double(), c64[:, 0], c64[:, 1], c64[:, 2], spatial=True)
+    out = res if residual_only else O.generate_image(img.double(), res)
+    (out * w.double()).sum().backward()
+    got = ops.trispace_backward(img.to(dev), coeffs.to(dev), w.to(dev), residual_only=residual_only)
+    assert rel(got, c64.grad) <= 1e-4, rel(got, c64.grad)
+
+
 def test_trispace_backward_batch_geometry_consistent(ops, dev):
     """The training crop batch (32 x 256 x 256: 24 rows per thread, 11 row tiles) against the same images one at a time
     (16 rows per thread, 16 row tiles): the same sums in another order."""

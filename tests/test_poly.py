@@ -131,3 +131,24 @@ def test_twin_trispace_backward_column_strips(twin, residual_only):
     plain = twin.trispace_bwd(img.numpy(), coeffs.detach().numpy(), w.numpy(), residual_only)
     assert np.abs(got - plain).max() <= 2e-5 * np.abs(plain).max()
     assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("residual_only", [False, True])
+def test_twin_trispace_backward_on_8bit_content(twin, residual_only):
+    """The same on what the path is fed in production (infer.py:35-40: bytes / 255): a piece of the reference's own photograph
+    with black, white, grey and primary pixels written into it -- exact ties, exact zeros, generate_image's clamp at work --
+    against autograd through the oracle in FLOAT64."""
+    real = np.load(os.path.join(ROOT, "tests", "golden", "real8.npz"))
+    u8 = real["crop_u8"][100:112, 60:84].copy()
+    u8[0, :6] = [[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255]]
+    img = O.u8hwc_to_f32chw(u8)[None].repeat(2, 1, 1, 1)
+    g = torch.Generator().manual_seed(5 + residual_only)
+    coeffs = torch.randn(2, 3, 3, 126, generator=g) * 0.3
+    w = torch.randn(2, 3, 12, 24, generator=g)
+    c64 = coeffs.double().requires_grad_(True)
+    res = O.trispace_residual(img.double(), c64[:, 0], c64[:, 1], c64[:, 2], spatial=True)
+    out = res if residual_only else O.generate_image(img.double(), res)
+    (out * w.double()).sum().backward()
+    ref = c64.grad.numpy()
+    got = twin.trispace_bwd(img.numpy(), coeffs.numpy(), w.numpy(), residual_only)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), float(np.abs(got - ref).max() / np.abs(ref).max())
