@@ -644,6 +644,46 @@ def test_msssim_hip_odd_shapes_vs_torch_route(dev, shape):
     assert float((a1.grad - a2.grad).abs().max()) <= 1e-3 * float(a2.grad.abs().max())
 
 
+@pytest.mark.parametrize("case", ["identical", "constant", "black_vs_black", "black_vs_image", "saturated_patches"])
+def test_msssim_hip_special_images_vs_torch_route(dev, case):
+    """What evaluation meets and noise never produces (metric.py:120-211): identical images (every SSIM map is 1), constant
+    images (all variances 0: the ratio of the stabilising constants), black planes (masked-out regions), flat saturated
+    patches inside a photograph-like plane.  The fused statistics kernels against the stock-torch route of the same module
+    (forced by asking for a gradient of the second image), values and gradients, nothing NaN that is not NaN there."""
+    from curl_amd import metric
+    torch.manual_seed(4)
+    shape = (2, 1, 96, 80)
+    a = torch.rand(*shape, device=dev)
+    if case == "identical":
+        b = a.clone()
+    elif case == "constant":
+        a = torch.full(shape, 0.5, device=dev)
+        b = torch.full(shape, 0.25, device=dev)
+    elif case == "black_vs_black":
+        a = torch.zeros(shape, device=dev)
+        b = torch.zeros(shape, device=dev)
+    elif case == "black_vs_image":
+        b = torch.zeros(shape, device=dev)
+    else:
+        a[:, :, 10:50, 10:60] = 1.0
+        a[:, :, 60:90, 5:40] = 0.0
+        b = (a + 0.05 * torch.randn(*shape, device=dev)).clamp(0, 1)
+    m = metric.MSSSIMMetric(window_size=11, num_channel=1).to(dev)
+    a1 = a.clone().requires_grad_(True)
+    out = m(a1, b)
+    out.sum().backward()
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = m(a2, b2)
+    ref.sum().backward()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)), (out, ref)
+    ok = ~torch.isnan(ref)
+    assert float((out - ref)[ok].abs().max() if bool(ok.any()) else 0.0) <= 3e-6, (out, ref)
+    gn = torch.isnan(a2.grad)
+    assert torch.equal(torch.isnan(a1.grad), gn)
+    scale = float(a2.grad[~gn].abs().max()) if bool((~gn).any()) else 0.0
+    assert float((a1.grad - a2.grad)[~gn].abs().max() if bool((~gn).any()) else 0.0) <= 1e-3 * scale + 1e-9, scale
+
+
 def test_train_driver_reads_the_reference_folder_layout(dev, tmp_path):
     """--training_img_dirpath <dir>: main.py:196-210's layout (input / output / mask folders, images_train.txt,
     images_valid.txt) through curl_amd.data, one epoch with validation."""
