@@ -45,9 +45,27 @@ def reference_modules():
     return {"curves": curves, "colors": colors, "transpose": transpose, "metric": metric}
 
 
-@pytest.fixture(scope="session")
-def twin():
-    """Test-only host build of curl_amd/csrc/curl_math.h (tests/twin/curl_twin.cpp)."""
+HIP_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="session", params=["rounding", "contracting"])
+def twin(request):
+    """Test-only host build of curl_amd/csrc/curl_math.h (tests/twin/curl_twin.cpp), twice; every twin test runs on both.
+    rounding:    g++, NO a*b+c contraction -- every operation rounds where the source says.
+    contracting: hipcc's own clang for the host with ITS default for HIP device code, -ffp-contract=fast-honor-pragmas: products
+                 are fused into fmas across statements wherever the optimiser likes, as in the kernels, and `#pragma clang fp
+                 contract(off)` is honoured as there (plain `fast`, CUDA's default, lets the backend fuse whatever the pragmas
+                 say).  Not the device's instruction selection, but the same middle end making the same kind of choice: the
+                 CPU-side net for round 4's class of bug -- sign(a*b - c*d) of EQUAL products coming out +-1
+                 (curl_math_loss.h) -- which the rounding twin cannot see."""
+    if request.param == "rounding":
+        return _twin("libcurl_twin.so", ["g++", "-O2", "-mfma", "-ffp-contract=off"])
+    if not os.path.exists(HIP_CLANG):
+        pytest.skip("hipcc's clang is not installed here")
+    return _twin("libcurl_twin_contracting.so", [HIP_CLANG, "-O2", "-mfma", "-ffp-contract=fast-honor-pragmas"])
+
+
+def _twin(name, compile_cmd):
     src = os.path.join(ROOT, "tests", "twin", "curl_twin.cpp")
     hdr = os.path.join(ROOT, "curl_amd", "csrc", "curl_math.h")
     hdr2 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_bwd.h")
@@ -55,10 +73,9 @@ def twin():
     hdr4 = os.path.join(ROOT, "curl_amd", "csrc", "curl_math_loss.h")
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libcurl_twin.so")
+    so = os.path.join(out_dir, name)
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2), os.path.getmtime(hdr3), os.path.getmtime(hdr4)):
-        subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                               "-DCURL_HOST_TWIN", "-Wno-unknown-pragmas", "-o", so, src])
+        subprocess.check_call(compile_cmd + ["-fPIC", "-shared", "-std=c++17", "-DCURL_HOST_TWIN", "-Wno-unknown-pragmas", "-o", so, src])
     lib = ctypes.CDLL(so)
     fp = ctypes.POINTER(ctypes.c_float)
 

@@ -77,6 +77,8 @@ def test_twin_backward_where_prediction_equals_target_and_at_black(twin):
     """torch.sign(0) = 0: where prediction and target are the same bits every L1 term's gradient vanishes, so the two colours
     must go through the same arithmetic (one converter for both; round 4 found the taped and the plain RGB2LAB an ulp apart).
     A black prediction: the clamp gate of model.py:55 on an L of exactly 0 passes the gradient in the reference."""
+    # (on both twins, conftest.py: sign(0) must survive a*b+c contraction -- without the pragmas of curl_math_loss.h the
+    # contracting one fails here, as the device did)
     pred, tgt, mask, n_same = equal_and_black_case()
     # (the cosine term is off here: at a black prediction its reference gradient is target / (1e-8 |target|) ~ 1e6 and would
     # be the whole scale; it has no gate at black and is covered by test_twin_backward)
