@@ -123,6 +123,16 @@ CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m
   }
 }
 
+// Masked PSNR (metric.py:35-47): one channel's squared error under the mask, (clamp(a) m - clamp(b) m)^2, added to acc.
+// Two ROUNDED products, then their difference: contracted into fma(a, m, -(b m)) -- hipcc's default -- equal images under a
+// fractional float mask left a rounding residue, 160 dB where the reference has +inf (round 4).
+CURL_HD float psnr_sq_err(float a, float b, float m, float acc) {
+#pragma clang fp contract(off)
+  const float pa_m = clamp01(a) * m, pb_m = clamp01(b) * m;  // metric.py:60-61, then :44
+  const float d = pa_m - pb_m;
+  return fmaf(d, d, acc);
+}
+
 // torch.sign (the L1 terms' backward): -1, 0, +1.  Device: two exact scalings by 2^100 take every nonzero float32 past +-1
 // (the smallest denormal: 2^-149 * 2^200 = 2^51; an overflow to +-inf is fine), then a median with -1 and +1 -- three plain
 // instructions instead of two compare + `v_cndmask ..., vcc` pairs.

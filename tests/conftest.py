@@ -200,6 +200,14 @@ def _twin(name, compile_cmd):
             return int(lib.twin_div_small_mismatches(int(dmax)))
 
         @staticmethod
+        def psnr_sums(a, b, mask):
+            """(sum of squared masked errors, sum of mask) of ONE image [3,H,W] (psnr.inc's per-pixel term)."""
+            a, b, mask = f32(a), f32(b), f32(mask)
+            sse, ms = ctypes.c_double(), ctypes.c_double()
+            lib.twin_psnr_sums(P(a), P(b), P(mask), ctypes.c_long(a.shape[-1] * a.shape[-2]), ctypes.byref(sse), ctypes.byref(ms))
+            return sse.value, ms.value
+
+        @staticmethod
         def u8_edges(x):
             x = f32(x).ravel()
             unit = np.empty(256, np.float32)

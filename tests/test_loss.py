@@ -97,6 +97,21 @@ def test_twin_backward_where_prediction_equals_target_and_at_black(twin):
         assert np.abs(got[0, :, 0, :n_same]).max() <= 1e-6 * scale   # identical pixels: nothing is left
 
 
+def test_twin_psnr_of_equal_images_is_infinite_under_any_mask(twin):
+    """metric.py:35-62: equal images have zero squared error -- `10 log10(max^2 / 0) = +inf`, which nanmean keeps -- under a
+    float mask with fractional values too: clamp(a) m - clamp(b) m is a difference of two equal ROUNDED products.  (On the
+    contracting twin, as on the device in round 4, an fma(a, m, -(b m)) leaves a residue: 160 dB.)  And a plain case vs the oracle."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(1, 3, 9, 13, generator=g) * 1.4 - 0.2
+    soft = torch.rand(1, 1, 9, 13, generator=g) * 0.9 + 0.05
+    sse, ms = twin.psnr_sums(a[0].numpy(), a[0].clone().numpy(), soft[0, 0].numpy())
+    assert sse == 0.0 and abs(ms - float(soft.sum())) < 1e-4
+    b = torch.rand(1, 3, 9, 13, generator=g)
+    sse, ms = twin.psnr_sums(a[0].numpy(), b[0].numpy(), soft[0, 0].numpy())
+    want = float(O.psnr(a, b, soft))
+    assert abs(10.0 * np.log10(1.0 / (sse / (3.0 * ms))) - want) < 1e-4
+
+
 @pytest.mark.parametrize("tag", ["loss", "rgb", "w5"])
 def test_msssim_host_mirror_vs_reference_golden(golden, tag):
     """curl_amd.metric.MSSSIMMetric (stock torch, separable window, no .cuda()) against outputs and gradients of

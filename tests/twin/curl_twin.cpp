@@ -385,6 +385,18 @@ int twin_trispace_bwd(const float* img, const float* coeffs, const float* gout, 
   else trispace_bwd_host<3>(img, coeffs, gout, gcoef, B, H, W, residual_only);
   return 0;
 }
+// masked PSNR's sums for one image (psnr.inc's per-pixel term in the kernel's float32; the kernel's block partials are summed in
+// float64, here everything is): sse = sum over 3 HW of (clamp(a) m - clamp(b) m)^2, msum = sum of m
+int twin_psnr_sums(const float* a, const float* b, const float* mask, long HW, double* sse, double* msum) {
+  double s = 0.0, ms = 0.0;
+  for (long i = 0; i < HW; ++i) {
+    const float m = mask ? mask[i] : 1.0f;
+    for (int c = 0; c < 3; ++c) s += (double)curlm::psnr_sq_err(a[c * HW + i], b[c * HW + i], m, 0.0f);
+    ms += m;
+  }
+  *sse = s, *msum = ms;
+  return 0;
+}
 // file-edge scalars: out[b] = u8_to_unit(b) for b = 0..255; q[i] = unit_to_u8(x[i])
 int twin_u8_edges(float* unit256, const float* x, unsigned char* q, long n) {
   for (int b = 0; b < 256; ++b) unit256[b] = curlm::u8_to_unit((float)b);
