@@ -120,3 +120,18 @@ def test_hot_kernel_instruction_counts_are_pinned(kernels):
         assert name in fp, name
         got = (fp[name]["n_inst"], fp[name]["n_valu"], fp[name]["n_trans"])
         assert got == want, (name, got, want)
+
+
+def test_bench_flop_counts_are_the_builds(kernels, tmp_path):
+    """bench.py's VALU rooflines divide by FLOP-per-pixel figures counted from the kernels' ISA (tools/flops_from_isa.py): a
+    kernel that loses a tenth of its instructions (round 4: CURLLoss backward, 415 -> 362) must not keep its old figure and
+    report a tenth more TFLOP/s.  The single-kernel straight-line rows, within 1 %."""
+    import bench
+    import flops_from_isa
+    path = tmp_path / "curl.s"
+    path.write_text(_ASM)
+    for workload, frag, px_per_lane in (("layer_bwd", "layer_bwd_kernelILi4ELi1ELb1E", 4), ("layer_bwd_knots", "layer_bwd_kernelILi4ELi1ELb0E", 4),
+                                        ("loss_bwd", "loss_terms_bwd_kernelILi4ELi1E", 4), ("loss_fwd", "loss_terms_kernelILi4ELi1E", 4)):
+        got = flops_from_isa.flop_per_lane(str(path), frag) / px_per_lane
+        want = bench.WORKLOADS[workload]["flop_px"]
+        assert abs(got - want) <= 0.01 * want, (workload, got, want)

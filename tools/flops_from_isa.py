@@ -41,6 +41,22 @@ def kernel_blocks(path, frag):
     return blocks
 
 
+def flop_per_lane(path, frag, all_blocks=True):
+    """FLOPs per lane of kernel `frag` in the assembly at `path` (all blocks, or the largest one): what bench.py's flop_px
+    figures are -- tests/test_build_resources.py holds them to the build."""
+    blocks = kernel_blocks(path, frag)
+    hot = [i for b in blocks for i in b] if all_blocks else max(blocks, key=lambda b: sum(1 for i in b if i.startswith("v_")))
+    total = 0
+    for i in hot:
+        if not i.startswith("v_"):
+            continue
+        for pat, f in FLOPS:
+            if re.match(pat, i):
+                total += f
+                break
+    return total
+
+
 def main():
     path, frag = sys.argv[1], sys.argv[2]
     ppl = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("-") else 4
