@@ -576,10 +576,19 @@ def main():
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CURL_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")  # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist_mod.init_process_group(backend="nccl", device_id=device)
-        else:
-            dist_mod.init_process_group(backend=backend)
+        # (gloo's C++ side prints its "[Gloo] Rank n is connected to ..." lines on fd 1: they go to stderr, stdout carries the
+        # ONE JSON line and nothing else)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist_mod.init_process_group(backend="nccl", device_id=device)
+            else:
+                dist_mod.init_process_group(backend=backend)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         dist = dist_mod
 
     from curl_amd import _lib, ops
