@@ -23,7 +23,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc's SLP vectoriser packs independent scalar float chains into v_pk_*_f32 with a shuffle per operand
 # -- the packed forms this library wants are written out (curl_math_poly.h); without the pass the CURLLoss kernels are 5 %
 # faster and nothing is slower (profiles/r02/noslp_ab.log)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-math-errno", "-fno-slp-vectorize"]
+# -ffp-contract=fast-honor-pragmas: hipcc's default for device code, spelled out because results depend on it -- products are
+# fused into fmas across statements, EXCEPT where a block says `#pragma clang fp contract(off)` (differences that feed a sign
+# or must cancel exactly: curl_math_loss.h, curl_math_bwd.h).  Plain `fast` would ignore those pragmas.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-math-errno", "-fno-slp-vectorize",
+         "-ffp-contract=fast-honor-pragmas"]
 
 
 def build(force=False, verbose=False):
