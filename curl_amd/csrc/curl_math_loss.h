@@ -149,7 +149,8 @@ CURL_HD float sign0(float x) {
 CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float gLp) {
   // The differences below feed torch.sign: contracted into fma(v s, cos, -cone_t) -- exact product minus rounded product -- a
   // difference of EQUAL cones is a rounding residue and its sign +-1, where the reference has sign(0) = 0 (found in round 4 with
-  // pred == target pixels; the host twin is built without contraction and never saw it).  Explicit fmaf's only in here.
+  // pred == target pixels; the g++ host twin is built without contraction and never saw it -- tests/conftest.py's second,
+  // contracting twin does).  Explicit fmaf's only in here.
 #pragma clang fp contract(off)
   Px p{pred.c0 * m, pred.c1 * m, pred.c2 * m}, t{tgt.c0 * m, tgt.c1 * m, tgt.c2 * m};
   // rgb L1
