@@ -12,8 +12,10 @@ ITSELF as a child process -- before anything touches the GPU -- relays its outpu
 A step = one pass of the hot path over one batch: CURLLayer.forward (model.py:137-176) as the fused
 HIP kernel (RGB->Lab->curves->RGB->curves->HSV->curves->RGB + residual), inputs resident in HBM.
 Batches shard by image across ranks with NO data-path collective (weak scaling, 32 images per GPU).
-Rank 0 prints ONE JSON line.  Secondary workloads (RGB-only curves = BASELINE configs[1], the fused
-Lab stage the 70 % target is quoted on) ride along in "other_workloads".
+Rank 0 prints ONE compact JSON line on stdout (make_line: the contract's keys, `roofline`, `cpu_baseline`, four accuracy
+scalars and the literal-protocol figure; <= 4 KB, strict JSON -- tests/test_host_logic.py holds it to that).  Everything
+else (the other workloads' rows, the end-to-end and train-step records, the full accuracy block, board power) goes to
+bench_detail.json (beside this file and under gpurun_out/) and to stderr, never stdout.
 """
 import argparse
 import json
@@ -140,15 +142,19 @@ def make_step(name, ops, masks, sets=None):
                 turn[0] += 1
                 return ops.curl_layer_backward(c[0], m, c[1], c[2], c[3], gout, workspace=wss[k], need_grad_img=need_img)
             return crop_step
-        gout = sets[1 % len(sets)][0][:n]  # any resident float image serves as the incoming gradient
+        # any resident float image serves as the incoming gradient: the OTHER set's images n..2n, so that the gradient rotates
+        # with the inputs and no step finds its gradient stream where the last one left it (the MALL holds 256 MiB)
+        ids = {id(s): k for k, s in enumerate(sets)}
+        B_have = sets[0][0].shape[0]
+        lo = n if 2 * n <= B_have else 0
+        gouts = [sets[(k + 1) % len(sets)][0][lo:lo + n] for k in range(len(sets))]
         m = None if mask is None else mask[:n]
         if name in ("layer_bwd", "layer_bwd_knots"):
             ws8 = [ops.curl_layer_forward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], return_workspace=True)[2] for s in sets]
-            ids = {id(s): k for k, s in enumerate(sets)}
-            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gout, workspace=ws8[ids[id(s)]],
-                                                           need_grad_img=need_img)
+            return lambda s: ops.curl_layer_backward(s[0][:n], m, s[1][:n], s[2][:n], s[3][:n], gouts[ids[id(s)]],
+                                                           workspace=ws8[ids[id(s)]], need_grad_img=need_img)
         if name == "trispace_bwd":
-            return lambda s: ops.trispace_backward(s[0][:n], s[4][:n], gout)
+            return lambda s: ops.trispace_backward(s[0][:n], s[4][:n], gouts[ids[id(s)]])
         other = sets[1 % len(sets)][0]
         if name == "loss_fwd":
             return lambda s: ops.loss_term_sums(s[0], other, mask)
@@ -343,7 +349,7 @@ def accuracy_vs_oracle(ops, device):
             S = torch.maximum(S, (o - ref64).abs().amax(1) / 1e-6)
     S3 = S[:, None].expand_as(d)
     mse = float((d ** 2).sum() / (3 * mf.sum()))
-    psnr_vs_ref = float("inf") if mse == 0 else 10 * torch.log10(torch.tensor(1.0 / mse)).item()
+    psnr_vs_ref = None if mse == 0 else 10 * torch.log10(torch.tensor(1.0 / mse)).item()  # None: identical (strict JSON)
     p_out, p_ref = O.psnr(out, gt, mf), O.psnr(ref, gt, mf)
     return {
         "sample": "1 x 1500x1000 frame, knots N(0,0.1), bool disk mask, vs oracle (fp32 reference arithmetic)",
@@ -526,6 +532,104 @@ def load_traffic(kernel_fragment, workload=None):
     return None, None, None
 
 
+# what a scaling run (N > 1) measures beside the headline unless --full is given
+SCALING_RUN_WORKLOADS = ("lab_stage", "rgb_only")
+LINE_BUDGET = 4096  # bytes: the driver keeps an 8 KB tail of stdout; r04's 20.9 KB line could not be read back
+
+
+def _strict(x):
+    """inf / nan -> None, floats to 6 significant digits: the line must survive a strict JSON parser."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.6g}")
+    if isinstance(x, dict):
+        return {str(k): _strict(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict(v) for v in x]
+    return x
+
+
+def dump_line(line):
+    return json.dumps(_strict(line), allow_nan=False, separators=(", ", ": "))
+
+
+def _hbm_view(res):
+    r = res["roofline"]
+    return r if r["bound"] == "hbm" else r["secondary"]
+
+
+def make_line(main_res, others, accuracy, cpu, meta, train=None):
+    """The ONE stdout line: the contract's keys, the headline kernel's `roofline` (+ the scalars of the kernels north_star's
+    targets name: the fused Lab stage the 70 % figure is stated on, the HSV stage, RGB-only curves = BASELINE configs[1],
+    the layer on coherent 8-bit content), `cpu_baseline`, four accuracy scalars and the figure of the contract read
+    literally (no clock-settle launches).  `others` maps workload name -> measure() record.  Nothing here grows with the
+    workload table: that lives in bench_detail.json."""
+    world, B = meta["n_gpus"], meta["batch_per_gpu"]
+    r = main_res["roofline"]
+    roof = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+            "traffic": r["traffic"], "traffic_source": r.get("traffic_source"),
+            "achieved_wall": r["achieved_wall"], "frac_wall": r["frac_wall"], "valu_issue_util": r.get("valu_issue_util"),
+            "algorithmic_bytes_per_px": r["algorithmic_bytes_per_px"], "px_per_launch": r["px_per_launch"],
+            "kernel_us": main_res["device_ms_per_step"] * 1e3,
+            "timing": "HIP events on the launch stream over the timed region"}
+    for n in ("lab_stage", "hsv_stage", "rgb_only", "layer_8bit"):
+        o = others.get(n)
+        if o is not None:
+            hb = _hbm_view(o)
+            roof[f"{n}_us"] = o["device_ms_per_step"] * 1e3
+            roof[f"{n}_GBps"] = hb["achieved"]
+            roof[f"{n}_frac"] = hb["frac"]
+    cold = main_res.get("cold_start")
+    line = {
+        "metric": "Mpix/s through fused curve-apply at 1500x1000 bs32; PSNR delta vs ref",
+        "value": main_res["value"], "unit": "Mpix/s", "n_gpus": world, "steps": meta["steps"], "warmup": meta["warmup"],
+        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": main_res["workload"], "batch_per_gpu": B, "global_batch": B * world,
+                   "height": H_IMG, "width": W_IMG, "knots": "randn*0.1 (160 per image)",
+                   "parallelism": f"image-sharded x{world}, no data-path collective",
+                   "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
+                   "protocol": f"{CLOCK_SETTLE_LAUNCHES} untimed clock-settle launches precede the warm-up steps; "
+                               "literal_protocol_* = the same steps and warm-up from an idle chip without them"},
+        # the contract read literally beside the headline (cold_start_run: 0.5 s idle, W warm-up, K timed, wall clock)
+        "literal_protocol_ms_per_step": cold["ms_per_step"] if cold else None,
+        "literal_protocol_frac": (r["px_per_launch"] * r["algorithmic_bytes_per_px"] / (cold["ms_per_step"] * 1e-3) / 1e9
+                                  / HBM_PEAK_GBPS) if cold and r["bound"] == "hbm" else None,
+        "device_ms_per_step": main_res["device_ms_per_step"],
+        "roofline": roof,
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu_model") if k in cpu}
+    if accuracy is not None:
+        line["accuracy"] = {k: accuracy.get(k) for k in ("max_abs_err", "frac_px_over_1e-5", "psnr_delta_db",
+                                                         "max_err_per_unit_sensitivity")}
+    if world > 1:
+        line["ranks_seen"], line["backend"] = meta.get("ranks_seen"), meta.get("backend")
+        line["device_ms_per_step_min_over_ranks"] = main_res.get("device_ms_per_step_min_over_ranks")
+    if train and "error" not in train:
+        line["train_step"] = {k: train[k] for k in ("ms_per_step", "images_per_s", "curve_layer_share_of_step") if k in train}
+        if meta.get("gpus_visible", world) < world:
+            line["rehearsal"] = f"{world} ranks share {meta['gpus_visible']} GPU(s) over {meta.get('backend')}: not a scaling measurement"
+    line["detail"] = "bench_detail.json (also on stderr)"
+    return line
+
+
+def write_detail(detail):
+    """Everything that is not the line: to bench_detail.json beside bench.py, to gpurun_out/ (what a GPU box hands back)
+    and to stderr."""
+    txt = json.dumps(_strict(detail), allow_nan=False, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                f.write(txt + "\n")
+        except OSError:
+            pass
+    sys.stderr.write(json.dumps(_strict(detail), allow_nan=False) + "\n")
+    sys.stderr.flush()
+
+
 def self_launch(args):
     """`bench.py --gpus N` started without a launcher: start N ranks as a CHILD process (never exec: this process
     may not be replaced once a GPU is initialised, and nothing here has touched one yet) and relay its result."""
@@ -550,6 +654,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--workload", default="layer", choices=sorted(WORKLOADS))
     ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / cpu_baseline / accuracy")
+    ap.add_argument("--full", action="store_true", help="N > 1: measure the whole workload table, as N = 1 does")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -658,12 +763,16 @@ def main():
         return res
 
     main_res = measure(args.workload, args.steps, args.warmup, cold=True)
-    others = []
+    # N = 1: the whole table.  N > 1 (the scaling run): the headline, the two kernels north_star's targets name and the
+    # data-parallel train step -- the time goes to the scaling number; --full restores the table
+    names = [n for n in WORKLOADS if n != args.workload]
+    if world > 1 and not args.full:
+        names = [n for n in SCALING_RUN_WORKLOADS if n != args.workload]
+    others = {}
     if not args.no_extras:
-        for name in WORKLOADS:
-            if name != args.workload:
-                # >= 200 timed launches (>= 40 ms) each: the Lab-stage figure the 70 % target is quoted on rides here
-                others.append(measure(name, max(200, args.steps // 2), max(3, args.warmup // 2)))
+        for name in names:
+            # >= 200 timed launches (>= 40 ms) each: the Lab-stage figure the 70 % target is quoted on rides here
+            others[name] = measure(name, max(200, args.steps // 2), max(3, args.warmup // 2))
 
     train = None
     if not args.no_extras and os.environ.get("CURL_BENCH_TRAIN_STEP", "1") != "0":
@@ -688,49 +797,23 @@ def main():
             train = {"error": repr(e)}
 
     if rank == 0:
-        line = {
-            "metric": "Mpix/s through fused curve-apply at 1500x1000 bs32; PSNR delta vs ref",
-            "value": main_res["value"], "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": main_res["workload"], "batch_per_gpu": B, "global_batch": B * world,
-                       "height": H_IMG, "width": W_IMG, "knots": "randn*0.1 (160 per image)",
-                       "parallelism": f"image-sharded x{world}, no data-path collective"},
-            "device_ms_per_step": main_res["device_ms_per_step"],
-            "device_ms_per_step_min_over_ranks": main_res["device_ms_per_step_min_over_ranks"],
-            "cold_first_launch_us": main_res.get("cold_first_launch_us"),
-            "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
-            "ranks_seen": world if dist is None else dist.get_world_size(), "backend": backend,
-            "gpus_visible": n_dev,
-            "roofline": main_res["roofline"],
-        }
-        line["cold_start"] = main_res.get("cold_start")
-        # north_star's targets, driver-timed IN this run, where the driver's record keeps them (scalars of `roofline`): the
-        # fused Lab stage (the kernel the 70 % target is stated on), the HSV stage, RGB-only curves (BASELINE configs[1]) and
-        # the layer on coherent 8-bit content -- device time per launch from the events on the launch stream
-        by_name = {n: r for n, r in zip([n for n in WORKLOADS if n != args.workload], others)}
-        for n in ("lab_stage", "hsv_stage", "rgb_only", "layer_8bit"):
-            r = by_name.get(n)
-            if r is not None:
-                hb = r["roofline"] if r["roofline"]["bound"] == "hbm" else r["roofline"]["secondary"]
-                line["roofline"][f"{n}_us"] = r["device_ms_per_step"] * 1e3
-                line["roofline"][f"{n}_GBps"] = hb["achieved"]
-                line["roofline"][f"{n}_frac"] = hb["frac"]
-        if "power" in main_res:
-            line["power"] = main_res["power"]
-        if n_dev < world:
-            line["rehearsal"] = f"{world} ranks share {n_dev} GPU(s) over {backend}: not a scaling measurement"
+        meta = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "batch_per_gpu": B, "backend": backend,
+                "ranks_seen": world if dist is None else dist.get_world_size(), "gpus_visible": n_dev}
+        accuracy = end = cpu = None
         if not args.no_extras:
-            line["other_workloads"] = others
-            line["accuracy"] = accuracy_vs_oracle(ops, device)
-            try:
-                line["end_to_end"] = end_to_end(ops, device, sets, masks)
-            except Exception as e:  # context only: never at the expense of the line
-                line["end_to_end"] = {"error": repr(e)}
-            line["end_to_end"]["train_step"] = train
+            accuracy = accuracy_vs_oracle(ops, device)
+            if world == 1 or args.full:
+                try:
+                    end = end_to_end(ops, device, sets, masks)
+                except Exception as e:  # context only: never at the expense of the line
+                    end = {"error": repr(e)}
             # rank 0's host cores, after every timed region (the other ranks wait at the closing barrier)
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
+            cpu = cpu_baseline()
+        line = make_line(main_res, others, accuracy, cpu, meta, train)
+        detail = {"line": line, "headline": main_res, "other_workloads": others, "accuracy": accuracy,
+                  "end_to_end": end, "train_step": train, "cpu_baseline": cpu, "meta": meta}
+        write_detail(detail)
+        print(dump_line(line))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()

@@ -486,12 +486,17 @@ class _LossTermsFn(torch.autograd.Function):
         sums, Lp, Lt = ops.loss_term_sums(pred, target, mask)
         s = sums.sum(0)
         n = float(pred.shape[0] * pred.shape[2] * pred.shape[3])
-        unmasked = 3.0 * s[4]
+        # A mask of ONE image ([1,1,H,W] or [1,H,W]: ops._mask) is expanded over the batch for the
+        # kernel: its sum s[4] and its zeros are then counted `rep` times.  model.py:90 takes mask.sum() of the mask AS GIVEN
+        # (so the three L1 terms are rep times larger than with a [B,1,H,W] copy of it), while model.py:98's mean runs over
+        # the broadcast tensor (zeros counted per image).
+        rep = 1 if mask is None else pred.shape[0] // mask.shape[0]
+        unmasked = 3.0 * s[4] / rep
         rgb, lab, hsv = s[0] / unmasked, s[2] / unmasked, s[3] / unmasked
         # model.py:98 adds torch.logical_not(mask) -- 1 where the mask is EXACTLY 0 -- and takes the mean over the broadcast
         # [B,B,H,W].  bool / uint8 masks (data.py:190): their zeros are n - sum; a float mask with values strictly inside
-        # (0, 1) has none of those counted, so its zeros are counted as such.
-        n_zero = (mask == 0).sum().double() if (mask is not None and mask.is_floating_point()) else n - s[4]
+        # (0, 1) has none of those counted, so its zeros are counted as such (on the mask as given, times `rep`).
+        n_zero = (mask == 0).sum().double() * rep if (mask is not None and mask.is_floating_point()) else n - s[4]
         cosine = 1.0 - s[1] / n - n_zero / n
         ctx.save_for_backward(pred, target, unmasked)
         ctx.mask, ctx.n = mask, n

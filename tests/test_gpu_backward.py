@@ -386,6 +386,34 @@ def test_curl_loss_float_mask_strictly_inside_the_unit_interval(dev):
     assert float(torch.quantile(d.flatten(), 0.995)) <= 2e-4 * float(pc.grad.abs().max())
 
 
+@pytest.mark.parametrize("kind", ["bool", "binary_float", "fractional_float"])
+def test_curl_loss_one_image_mask_broadcast_over_the_batch(dev, kind):
+    """a [1,1,H,W] mask at B > 1 (ops._mask expands it for the kernel).  model.py:90 sums the mask AS GIVEN (one
+    image's worth) while model.py:98's mean counts its zeros once per image: value and gradient against the oracle, which
+    broadcasts as the reference does."""
+    import curl_oracle as O
+    from curl_amd import model
+    g = torch.Generator().manual_seed(28)
+    B = 3
+    pred, tgt = torch.rand(B, 3, 24, 40, generator=g), torch.rand(B, 3, 24, 40, generator=g)
+    m = torch.rand(1, 1, 24, 40, generator=g)
+    mask = {"bool": m > 0.3, "binary_float": (m > 0.3).float(), "fractional_float": torch.where(m > 0.3, m, torch.zeros(()))}[kind]
+    p = pred.to(dev).requires_grad_(True)
+    got = model.CURLLoss(msssim_layer=None)(p, tgt.to(dev), mask.to(dev))
+    got.backward()
+    md = mask if kind == "bool" else mask.double()
+    pc = pred.clone().double().requires_grad_(True)
+    want = O.curl_loss(pc, tgt.double(), md, torch.tensor(0.0, dtype=torch.float64))
+    want.backward()
+    assert abs(float(got) - float(want)) <= 3e-6 * max(1.0, abs(float(want))), (float(got), float(want))
+    d = (p.grad.cpu().double() - pc.grad).abs()
+    assert float(torch.quantile(d.flatten(), 0.995)) <= 2e-4 * float(pc.grad.abs().max())
+    # and the same mask given per image: the L1 terms are then B times smaller, the cosine term the same
+    full = model.CURLLoss(msssim_layer=None)(pred.to(dev), tgt.to(dev), mask.expand(B, 1, 24, 40).contiguous().to(dev))
+    want_full = O.curl_loss(pred.double(), tgt.double(), md.expand(B, 1, 24, 40), torch.tensor(0.0, dtype=torch.float64))
+    assert abs(float(full) - float(want_full)) <= 3e-6 and abs(float(full) - float(got)) > 1e-3
+
+
 def test_curl_loss_with_msssim_vs_oracle(dev):
     """The module as the reference builds it (model.py:48: MS-SSIM of the clamped L planes, window 11), value and
     gradient against the oracle's restatement (pinned by the reference's own class, golden msssim.npz)."""

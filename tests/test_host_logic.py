@@ -324,3 +324,88 @@ def test_bench_workload_table_and_replayed_traffic():
     traffic, src, _util = bench.load_traffic("OpLayer")
     assert 1.15e9 < traffic < 1.3e9 and src.startswith("profiles/traffic_r") and "not this run" in src
     assert bench.load_traffic("NoSuchKernel", "no_such_workload") == (None, None, None)
+
+
+def _fake_measure_record(bench, name, ms):
+    """A measure() record of bench.py's shape for one workload, with awkward floats (what a real run prints)."""
+    w = bench.WORKLOADS[name]
+    npx = bench.workload_pixels(name, 32)
+    gbps = npx * w["bpp"] / (ms * 1e-3) / 1e9
+    tf = npx * w["flop_px"] / (ms * 1e-3) / 1e12
+    hbm = {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "frac_of_measured_copy_ceiling_6585": gbps / 6585.0}
+    valu = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "flop_per_px": w["flop_px"]}
+    roof = dict(hbm if w["bound"] == "hbm" else valu)
+    roof.update({"bound": w["bound"], "traffic": 1205276956.6711411, "traffic_source": "profiles/traffic_r04.json (builder's "
+                 "rocprofv3 --pmc pass, not this run)", "valu_issue_util": 0.8361234567, "achieved_wall": gbps * 0.97,
+                 "frac_wall": gbps * 0.97 / 8000.0, "value_from_event_clock_Mpix_s": npx / (ms * 1e-3) / 1e6,
+                 "algorithmic_bytes_per_px": w["bpp"], "px_per_launch": npx,
+                 "secondary": {"bound": "valu", **valu} if w["bound"] == "hbm" else {"bound": "hbm", **hbm}})
+    return {"workload": w["desc"], "value": npx / (ms * 1e-3) / 1e6 * 0.97, "ms_per_step": ms / 0.97, "device_ms_per_step": ms,
+            "device_ms_per_step_min_over_ranks": ms, "roofline": roof,
+            "cold_first_launch_us": 431.123456789,
+            "cold_start": {"ms_per_step": 0.2634567891, "value": 1.8e5, "unit": "Mpix/s per GPU", "protocol": "x" * 120},
+            "power": {"board_power_W_mean": 1399.2, "board_power_cap_W": 1400.0, "shader_clock_MHz_mean": 1931.0, "samples": 70}}
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_bench_line_is_compact_strict_json_with_the_contract_keys(world):
+    """round 4's 20.9 KB line could not be read back by the driver.  The stdout line is built in ONE
+    function from the measure() records; with the whole workload table measured it stays under 4 KB, parses under a strict
+    JSON parser (inf / nan -> null) and carries every key the contract names, `roofline` and `cpu_baseline`."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    main_res = _fake_measure_record(bench, "layer", 0.19809123456789)
+    others = {n: _fake_measure_record(bench, n, 0.1888 + 0.01 * k) for k, n in enumerate(bench.WORKLOADS) if n != "layer"}
+    assert len(others) >= 16
+    accuracy = {"sample": "s" * 100, "max_abs_err": 2.37e-5, "frac_px_over_1e-5": 2.2e-5, "psnr_delta_db": 1.2e-7,
+                "max_err_per_unit_sensitivity": 1.9e-6, "psnr_out_vs_ref_db": float("inf"), "reg_rel_err": float("nan")}
+    cpu = {"value": 2.3812345678, "unit": "Mpix/s", "cores": 16, "kind": "port", "sample": "4 x 1500x1000 frames through the "
+           "full chain (oracle/curl_oracle.py curl_layer, all-ones mask), median of 3, torch 2.10.0+rocm7.0 CPU, 16 threads of "
+           "256 host cpus", "cpu_model": "AMD EPYC 9575F 64-Core Processor", "host_cpus": 256,
+           "legs": {"a": {"Mpix/s": 1.0, "threads": 16}}}
+    meta = {"n_gpus": world, "steps": 20, "warmup": 5, "batch_per_gpu": 32, "backend": "nccl" if world > 1 else None,
+            "ranks_seen": world, "gpus_visible": world}
+    train = {"ms_per_step": 61.3, "images_per_s": 4170.0, "curve_layer_share_of_step": 0.012, "model": "m" * 200}
+    line = bench.make_line(main_res, others, accuracy, cpu, meta, train)
+    txt = bench.dump_line(line)
+    assert "\n" not in txt and len(txt.encode()) <= bench.LINE_BUDGET <= 4096, len(txt)
+
+    def refuse(tok):
+        raise ValueError(tok)
+    d = json.loads(txt, parse_constant=refuse)  # Infinity / NaN would raise here
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == world and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["metric"].startswith("Mpix/s through fused curve-apply") and "model" not in d["config"]
+    assert d["config"]["workload"].startswith("CURLLayer.forward") and d["config"]["global_batch"] == 32 * world
+    assert d["config"]["clock_settle_launches"] == bench.CLOCK_SETTLE_LAUNCHES
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and 0.7 < r["frac"] < 0.8
+    assert r["traffic"] > 1e9 and r["valu_issue_util"] is not None and r["achieved_wall"] < r["achieved"]
+    for n in ("lab_stage", "hsv_stage", "rgb_only", "layer_8bit"):
+        assert r[f"{n}_us"] > 0 and r[f"{n}_GBps"] > 0 and 0 < r[f"{n}_frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 16 and c["value"] > 0 and c["unit"] == "Mpix/s" and "legs" not in c
+    # both protocols lead the record (VERDICT r4 item 7): the figure with the settle launches and the literal one
+    assert abs(d["literal_protocol_ms_per_step"] - 0.263457) < 1e-6
+    assert abs(d["literal_protocol_frac"] - 48e6 * 25 / 0.263457e-3 / 1e9 / 8000) < 1e-3
+    assert set(d["accuracy"]) == {"max_abs_err", "frac_px_over_1e-5", "psnr_delta_db", "max_err_per_unit_sensitivity"}
+    assert "other_workloads" not in d and "end_to_end" not in d and "power" not in d
+    # the strict dump maps non-finite floats to null wherever they sit
+    assert json.loads(bench.dump_line({"a": float("inf"), "b": [float("nan"), 1.0]})) == {"a": None, "b": [None, 1.0]}
+    # a slim run (no extras): still a valid line
+    bare = bench.dump_line(bench.make_line(main_res, {}, None, None, meta))
+    assert json.loads(bare)["roofline"]["frac"] == r["frac"]
+
+
+def test_scaling_run_measures_the_targets_only():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert set(bench.SCALING_RUN_WORKLOADS) == {"lab_stage", "rgb_only"} and set(bench.SCALING_RUN_WORKLOADS) < set(bench.WORKLOADS)
