@@ -105,6 +105,33 @@ def load():
     return lib
 
 
+_fast = None
+# the entry points csrc/fastcall.cpp calls (their addresses in the library load() bound: CURL_HIP_LIB may name a variant)
+FASTCALL_ABI = ("curl_layer_fwd_f32", "curl_layer_bwd_f32", "curl_trispace_fwd_u8hwc", "curl_workspace_bytes",
+                "curl_layer_bwd_scratch_bytes")
+
+
+def fast():
+    """The compiled binding of the three hot entry points (curl_amd/_fastcall.*.so, csrc/fastcall.cpp), bound to the library
+    load() loaded.  Like the library itself it is part of the build: absent -> ImportError.  CURL_NO_FASTCALL=1 selects the
+    ctypes surface for every call (the A/B of the two host paths, tools/small_batch.py)."""
+    global _fast
+    if _fast is not None:
+        return _fast or None
+    if os.environ.get("CURL_NO_FASTCALL", "0") == "1":
+        _fast = False
+        return None
+    lib = load()
+    try:
+        from . import _fastcall
+    except ImportError as e:
+        raise ImportError(f"curl_amd: the compiled binding curl_amd/_fastcall.*.so is missing or does not load ({e}). Build it "
+                          "with `python -m curl_amd.build` (g++, a torch C++ extension).") from e
+    _fastcall.bind_abi({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in FASTCALL_ABI})
+    _fast = _fastcall
+    return _fast
+
+
 def check(rc, what):
     """Translate a C-ABI return code into the Python exception the reference's callers would see:
     argument errors -> ValueError (torch raises on bad shapes), HIP errors -> CurlHipError."""

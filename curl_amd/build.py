@@ -1,4 +1,5 @@
-"""Build libcurlhip.so for gfx950 with hipcc (cross-compiles without a GPU).
+"""Build libcurlhip.so for gfx950 with hipcc (cross-compiles without a GPU), and the compiled host-side binding of its three
+hot entry points (csrc/fastcall.cpp -> curl_amd/_fastcall.*.so: a torch C++ extension, host code only, g++).
 
     python -m curl_amd.build            # or __graft_entry__.build()
 """
@@ -45,5 +46,37 @@ def build(force=False, verbose=False):
     return OUT
 
 
+FAST_SRC = os.path.join(HERE, "csrc", "fastcall.cpp")
+
+
+def fastcall_path():
+    import sysconfig
+    return os.path.join(HERE, "_fastcall" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_fastcall(force=False):
+    """g++ csrc/fastcall.cpp -> curl_amd/_fastcall.<abi>.so against the torch this interpreter imports (host code: tensors in,
+    the C ABI underneath; the kernels' library is not linked -- _lib.py hands its function addresses over at import)."""
+    import sysconfig
+    import torch
+    out = fastcall_path()
+    deps = [FAST_SRC, INCLUDE, os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    tdir = os.path.dirname(torch.__file__)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_fastcall", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include",
+           f"-I{sysconfig.get_paths()['include']}", FAST_SRC, "-o", out,
+           f"-L{tdir}/lib", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python", f"-Wl,-rpath,{tdir}/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("g++ failed building the _fastcall binding")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_fastcall(force="--force" in sys.argv))

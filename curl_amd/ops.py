@@ -321,13 +321,28 @@ def hsv_stage(img, mask, H, flags=0, out=None):
     return out, reg
 
 
-@_one_device
-@_empty_ok(mask_arg=0)
 def curl_layer_forward(img, mask, L, R, H, flags=0, out=None, return_workspace=False):
     """CURLLayer.forward (model.py:137-176) in one pass over the pixels. -> (img, reg[B]).
     L [B,3*Kl], R [B,3*Kr], H [B,4*Kh] are the already-sliced raw knots.
     return_workspace: also return the knot workspace the call filled (-> (img, reg, ws)); handed back to
-    curl_layer_backward(..., workspace=ws) it saves that call its knot-prep launch."""
+    curl_layer_backward(..., workspace=ws) it saves that call its knot-prep launch.
+    The plain call (every tensor on the current device, float32, contiguous, even knot counts) goes through the
+    compiled binding (csrc/fastcall.cpp: one Python -> C++ transition); anything else -- and every error -- through the
+    checked path below."""
+    if type(img) is torch.Tensor:
+        fast = _lib.fast()
+        if fast is not None:
+            r = fast.layer_fwd(img, mask, L, R, H, flags, out)
+            if r is not None:
+                if r.__class__ is int:
+                    _lib.check(r, "curl_layer_fwd_f32")
+                return r if return_workspace else r[:2]
+    return _curl_layer_forward_checked(img, mask, L, R, H, flags=flags, out=out, return_workspace=return_workspace)
+
+
+@_one_device
+@_empty_ok(mask_arg=0)
+def _curl_layer_forward_checked(img, mask, L, R, H, flags=0, out=None, return_workspace=False):
     lib = _lib.load()
     img = _image(img)
     B, _, Hh, W = img.shape
@@ -394,11 +409,24 @@ def trispace_forward_rows(img, coeffs, rows, out, residual_only=False):
     return out
 
 
-@_one_device
 def curl_layer_backward(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True, workspace=None, flags=0):
     """Backward of curl_layer_forward (what autograd would run through model.py:137-176).
     -> (grad_img or None, grad_L, grad_R, grad_H).
-    workspace: the tensor curl_layer_forward(..., return_workspace=True) returned for the SAME knots (CURL_F_WS_READY)."""
+    workspace: the tensor curl_layer_forward(..., return_workspace=True) returned for the SAME knots (CURL_F_WS_READY).
+    (Plain calls through the compiled binding, as curl_layer_forward.)"""
+    fast = _lib.fast() if type(img) is torch.Tensor else None
+    if fast is not None:
+        r = fast.layer_bwd(img, mask, L, R, H, grad_out, grad_reg, need_grad_img, workspace, flags & F_MASK_FIRST)
+        if r is not None:
+            if r.__class__ is int:
+                _lib.check(r, "curl_layer_bwd_f32")
+            return r
+    return _curl_layer_backward_checked(img, mask, L, R, H, grad_out, grad_reg=grad_reg, need_grad_img=need_grad_img,
+                                        workspace=workspace, flags=flags)
+
+
+@_one_device
+def _curl_layer_backward_checked(img, mask, L, R, H, grad_out, grad_reg=None, need_grad_img=True, workspace=None, flags=0):
     lib = _lib.load()
     img = _image(img)
     grad_out = _image(grad_out, "grad_out")
@@ -559,10 +587,22 @@ def _white(white_mask, img_u8):
     return white_mask.contiguous()
 
 
-@_one_device
 def trispace_forward_u8hwc(img_u8, coeffs, white_mask=None):
     """infer.py:35-47 on the file's own bytes, one launch: byte/255 -> generate_residual + generate_image ->
-    [out*m + (1-m), m = white_mask/255] -> truncating *255.  img_u8 [B,H,W,3] uint8 -> [B,H,W,3] uint8."""
+    [out*m + (1-m), m = white_mask/255] -> truncating *255.  img_u8 [B,H,W,3] uint8 -> [B,H,W,3] uint8.
+    (Plain calls through the compiled binding, as curl_layer_forward.)"""
+    fast = _lib.fast() if type(img_u8) is torch.Tensor else None
+    if fast is not None:
+        r = fast.trispace_fwd_u8hwc(img_u8, coeffs, white_mask)
+        if r is not None:
+            if r.__class__ is int:
+                _lib.check(r, "curl_trispace_fwd_u8hwc")
+            return r
+    return _trispace_forward_u8hwc_checked(img_u8, coeffs, white_mask=white_mask)
+
+
+@_one_device
+def _trispace_forward_u8hwc_checked(img_u8, coeffs, white_mask=None):
     lib = _lib.load()
     x = _bytes_image(img_u8)
     B, H, W, _ = x.shape

@@ -161,3 +161,20 @@ def test_public_header_compiles_as_c99_and_cxx(tmp_path):
     txt = open(HEADER).read()
     assert "torch" not in txt.lower().replace("pytorch's caching allocator", "") or "at::" not in txt
     assert "hip/hip_runtime" not in txt
+
+
+def test_fastcall_binding_builds_loads_and_declines_cpu_tensors():
+    """The compiled binding of the three hot entry points (csrc/fastcall.cpp): built in-tree next to the library, bound to the
+    addresses of the library _lib loaded, and -- without a GPU -- answering None (= "take the checked path") for CPU tensors.
+    No compute call happens here."""
+    import torch
+    from curl_amd import _lib
+    from curl_amd.build import build_fastcall, fastcall_path
+    assert build_fastcall() == fastcall_path()
+    assert set(_lib.FASTCALL_ABI) <= set(_lib.SIGNATURES)
+    fast = _lib.fast()
+    assert fast is not None and {"layer_fwd", "layer_bwd", "trispace_fwd_u8hwc", "bind_abi"} <= set(dir(fast))
+    img, k48, k64 = torch.zeros(1, 3, 4, 4), torch.zeros(1, 48), torch.zeros(1, 64)
+    assert fast.layer_fwd(img, None, k48, k48, k64, 0) is None
+    assert fast.layer_bwd(img, None, k48, k48, k64, img, None, True, None, 0) is None
+    assert fast.trispace_fwd_u8hwc(torch.zeros(1, 4, 4, 3, dtype=torch.uint8), torch.zeros(1, 3, 3, 126), None) is None

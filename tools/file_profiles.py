@@ -18,7 +18,8 @@ sys.path.insert(0, HERE)
 from pmc_summary import main as summarise  # noqa: E402
 
 # the workload's dominant kernel (the summary and the per-launch series are its; traffic_<tag>.json sums a call's kernels)
-FRAG = {"layer": "OpLayer", "layer_8bit": "OpLayer", "lab_stage": "OpLabStage", "hsv_stage": "OpHsvStage", "rgb_only": "OpAdjust3",
+FRAG = {"layer": "OpLayer", "layer_8bit": "OpLayer", "layer_disk": "OpLayer", "layer_disk_mask_first": "OpLayer", "layer_u8": "OpLayer",
+        "trispace_u8": "OpTriSpace", "lab_stage": "OpLabStage", "hsv_stage": "OpHsvStage", "rgb_only": "OpAdjust3",
         "trispace": "OpTriSpace", "layer_bwd": "layer_bwd_kernel", "layer_bwd_crop": "layer_bwd_kernel",
         "layer_bwd_knots": "layer_bwd_kernel", "layer_bwd_crop_knots": "layer_bwd_kernel",
         "loss_fwd": "loss_terms_kernel", "loss_bwd": "loss_terms_bwd_kernel", "trispace_bwd": "trispace_coef_grad"}

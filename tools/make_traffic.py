@@ -21,7 +21,8 @@ from pmc_summary import load_counters, load_trace  # noqa: E402
 
 # workload -> kernel-name fragments of the kernels one call launches (knots_prep_kernel: 640 B per image, left out)
 KERNELS = {
-    "layer": ["OpLayer"], "layer_8bit": ["OpLayer"], "lab_stage": ["OpLabStage"], "hsv_stage": ["OpHsvStage"],
+    "layer": ["OpLayer"], "layer_8bit": ["OpLayer"], "layer_disk": ["OpLayer"], "layer_disk_mask_first": ["OpLayer"],
+    "layer_u8": ["OpLayer"], "trispace_u8": ["OpTriSpace"], "lab_stage": ["OpLabStage"], "hsv_stage": ["OpHsvStage"],
     "rgb_only": ["OpAdjust3"], "trispace": ["OpTriSpace"],
     "layer_bwd": ["layer_bwd_kernel", "knots_bwd_kernel"], "layer_bwd_crop": ["layer_bwd_kernel", "knots_bwd_kernel"],
     "layer_bwd_knots": ["layer_bwd_kernel", "knots_bwd_kernel"], "layer_bwd_crop_knots": ["layer_bwd_kernel", "knots_bwd_kernel"],
