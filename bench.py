@@ -92,9 +92,9 @@ WORKLOADS = {
     # rooflined against the 157.3 TFLOP/s vector peak; flop_px from the kernels' ISA (tools/flops_from_isa.py --all)
     "layer_bwd": dict(desc="curve-layer BACKWARD (curl_layer_bwd_f32: d img + d raw knots; autograd of model.py:137-176, the "
                            "forward's knot workspace handed back as the autograd node does) on 8 x 1500x1000 frames, bool mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu",
-                      flop_px=412.5, images=8),
+                      flop_px=413.5, images=8),
     "layer_bwd_crop": dict(desc="curve-layer backward on the training crop batch, 32 x 256x256 (main.py:88, data.py:86), bool "
-                                "mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu", flop_px=412.5,
+                                "mask all ones", bpp=37.0, frag="layer_bwd_kernel", mask="ones", bound="valu", flop_px=413.5,
                            images=32, hw=(256, 256)),
     "layer_bwd_knots": dict(desc="curve-layer backward, knot gradients only (grad_img = NULL: what the training step runs, the image "
                                  "being data -- main.py:287): no RGB2LAB pullback, no gradient image written; 8 x 1500x1000 frames",
@@ -105,7 +105,7 @@ WORKLOADS = {
                           "and target + the two L planes), bool mask all ones", bpp=33.0, frag="loss_terms_kernel",
                      mask="ones", bound="valu", flop_px=241.2),
     "loss_bwd": dict(desc="CURLLoss pointwise terms backward (gradient w.r.t. the prediction)", bpp=41.0,
-                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=362.0),
+                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=356.0),
     "trispace_bwd": dict(desc="polynomial path backward (curl_trispace_bwd_f32: d loss / d 3x3x126 coefficients, main.py:287) "
                               "on 8 x 1500x1000 frames: three kernels, 72 B/px of intermediates between the first two",
                          bpp=24.0, frag="trispace_bwd", mask=None, bound="valu", flop_px=3059.0, images=8),

@@ -40,9 +40,13 @@ CURL_HD void cos_sin_turns(float h, float& c, float& s) {
 #endif
 }
 
-CURL_HD Px hsv_cone(Px hsv) {  // model.py:65-76 on clamp(rgb2hsv(x), 0, 1)
+// model.py:65-76 on clamp(rgb2hsv(x), 0, 1).  That clamp is the identity: RGB2HSV ends in clamp(., 1e-9, 1) (colors.py:240,
+// rgb2hsv_n / rgb2hsv_t), so h, s, v arrive in [1e-9, 1] and torch.clamp's gradient gate [0 <= x <= 1] always passes --
+// round 5 took the three clamps per colour and the three gates of the backward out of the kernels (6 of 241 and 21 of 410
+// instructions per pixel; same bits: a clamp of a value inside its interval returns it).
+CURL_HD Px hsv_cone(Px hsv) {
 #pragma clang fp contract(off)  // (equal colours -> equal cones, whatever the caller does with them: loss_terms_bwd)
-  float h = clamp01(hsv.c0), s = clamp01(hsv.c1), v = clamp01(hsv.c2);
+  float h = hsv.c0, s = hsv.c1, v = hsv.c2;
   float ca, sa;
   cos_sin_turns(h, ca, sa);
   return Px{v * s * ca, v * s * sa, v};
@@ -103,7 +107,7 @@ CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m
     rgb2hsv_n<2 * N>(hsv);  // model.py:107-109
     float ca[2 * N], sa[2 * N];
 #pragma unroll
-    for (int i = 0; i < 2 * N; ++i) ca[i] = clamp01(hsv.c0[i]);
+    for (int i = 0; i < 2 * N; ++i) ca[i] = hsv.c0[i];  // (model.py:66's clamp is the identity on RGB2HSV's output: hsv_cone)
     CURL_FENCE();
     CURL_TRANS_BEGIN();
 #pragma unroll
@@ -116,8 +120,8 @@ CURL_HD void loss_terms_n(const PxN<N>& pred, const PxN<N>& tgt, const float (&m
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int j = N + i;
-      const float vi = clamp01(hsv.c2[i]), vj = clamp01(hsv.c2[j]);
-      const float ri = vi * clamp01(hsv.c1[i]), rj = vj * clamp01(hsv.c1[j]);
+      const float vi = hsv.c2[i], vj = hsv.c2[j];
+      const float ri = vi * hsv.c1[i], rj = vj * hsv.c1[j];
       sum[3] += (fabsf(ri * ca[i] - rj * ca[j]) + fabsf(ri * sa[i] - rj * sa[j])) + fabsf(vi - vj);
     }
   }
@@ -183,11 +187,11 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
   Px hp = rgb2hsv_t(p, tape_hsv);
   Px cp = hsv_cone(hp), ct = hsv_cone(rgb2hsv_t(t, tape_hsv_unused));
   float ge0 = w[3] * sign0(cp.c0 - ct.c0), ge1 = w[3] * sign0(cp.c1 - ct.c1), ge2 = w[3] * sign0(cp.c2 - ct.c2);
-  float h = clamp01(hp.c0), s = clamp01(hp.c1), v = clamp01(hp.c2);
+  float h = hp.c0, s = hp.c1, v = hp.c2;  // in [1e-9, 1]: model.py:66's clamp is the identity and its gate passes (hsv_cone)
   float ca, sa;
   cos_sin_turns(h, ca, sa);
   const float radial = fmaf(ge1, sa, ge0 * ca);
-  Px gh{kTwoPi * v * s * fmaf(ge1, ca, -(ge0 * sa)) * pass01(hp.c0), v * radial * pass01(hp.c1), fmaf(s, radial, ge2) * pass01(hp.c2)};
+  Px gh{kTwoPi * v * s * fmaf(ge1, ca, -(ge0 * sa)), v * radial, fmaf(s, radial, ge2)};
   Px g_hsv = rgb2hsv_pull(tape_hsv, gh);
   return Px{(g.c0 + g_lab.c0 + g_hsv.c0) * m, (g.c1 + g_lab.c1 + g_hsv.c1) * m, (g.c2 + g_lab.c2 + g_hsv.c2) * m};
 }

@@ -103,7 +103,8 @@ enum {
                                     handed for the SAME raw knots and has not been written since: it already holds the
                                     exp'd knots and collapsed curves, the knot-prep launch is skipped.  Every prepared row
                                     carries a stamp of the knot count and row stride it was filled for: a row nobody filled
-                                    for this call's shape (a zeroed buffer, another K) is answered with NaN knot gradients;
+                                    for this call's shape (a zeroed buffer, another K) is answered with NaN knot gradients
+                                    AND a NaN gradient image for that image (never a plausible-looking one);
                                     that the VALUES belong to these knots remains the caller's word */
 #define CURL_F_DIAG_SKIP_PREP 0x20000u /* DIAGNOSTICS ONLY (curl_layer_fwd_f32): the knot-prep launch is skipped and the
                                          workspace is taken to hold an earlier call's result for the same knots; `reg`

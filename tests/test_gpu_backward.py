@@ -897,12 +897,24 @@ def test_backward_refuses_a_workspace_nobody_filled(ops, dev):
     _, _, ws = ops.curl_layer_forward(img, None, L, R, Hk, return_workspace=True)
     ok = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=ws)
     assert all(torch.isfinite(t).all() for t in ok[1:])
+    assert torch.isfinite(ok[0]).all()
     bad = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=torch.zeros_like(ws))
     assert all(torch.isnan(t).all() for t in bad[1:])
+    assert torch.isnan(bad[0]).all()  # the gradient IMAGE of such a row is NaN too, not silent garbage
+    # one image's row bad, the other's good: the good image's gradients are untouched
+    half = ws.clone()
+    half.view(B, -1)[1].zero_()
+    mixed = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=half)
+    assert torch.equal(mixed[0][0], ok[0][0]) and torch.isnan(mixed[0][1]).all()
+    assert all(torch.equal(m[0], o[0]) and torch.isnan(m[1]).all() for m, o in zip(mixed[1:], ok[1:]))
+    # (the scalar path -- H*W not a multiple of 4 -- takes the same check)
+    i3, g3 = img[..., :15].contiguous(), gout[..., :15].contiguous()
+    _, _, ws3 = ops.curl_layer_forward(i3, None, L, R, Hk, return_workspace=True)
+    assert torch.isnan(ops.curl_layer_backward(i3, None, L, R, Hk, g3, workspace=torch.zeros_like(ws3))[0]).all()
     # the row of a forward with other knot counts (K = 8): same size class, another stamp
     L8, R8, H8 = ((torch.randn(B, n, generator=g) * 0.1).to(dev) for n in (24, 24, 32))
     _, _, ws8 = ops.curl_layer_forward(img, None, L8, R8, H8, return_workspace=True)
     big = torch.zeros_like(ws)
     big[:ws8.numel()] = ws8
     bad = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=big)
-    assert all(torch.isnan(t).all() for t in bad[1:])
+    assert all(torch.isnan(t).all() for t in bad) 
