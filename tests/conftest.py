@@ -25,7 +25,12 @@ def has_gpu():
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
-        return np.load(os.path.join(GOLDEN, name + ".npz"))
+        path = os.path.join(GOLDEN, name + ".npz")
+        if name == "real8" and not os.path.exists(path):
+            # the one fixture that holds third-party pixels (tests/golden/README.md): a tree shipped without it loses these
+            # tests, nothing else
+            pytest.skip("tests/golden/real8.npz not present (tests/golden/README.md)")
+        return np.load(path)
     return load
 
 

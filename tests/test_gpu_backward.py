@@ -149,7 +149,7 @@ def _mosaic_8bit():
 
 @pytest.mark.parametrize("case", ["random_s01", "random_s03", "coherent_8bit_dim_knots", "cube_slices_8bit_dim_knots", "fullsize_random_s01",
                                   "photograph_crop_dim_knots", "photograph_dark_dim_knots"])
-def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
+def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case, golden):
     """the backward's parity pinned the way the forward's is.  Yardstick: FLOAT64 autograd through the
     oracle (the reference's arithmetic).  Per pixel,
         |d img_HIP - d img_64| <= max(2e-6 * G, 2e-6 * C(pixel)),     G = max |d img_64|,
@@ -178,7 +178,7 @@ def test_backward_parity_is_pinned_to_float64_autograd(ops, dev, case):
     elif case.startswith("photograph"):
         # the reference's own photographs (tests/golden/real8.npz: configs[0]'s 256x256 crop, and the dark 512x341 frame whose
         # forward needs the conditioned bound on 2 pixels), the unsaturated knots B, the crop under its disk mask
-        real = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real8.npz"))
+        real = golden("real8")
         key = "crop" if "crop" in case else "dark"
         img = O.u8hwc_to_f32chw(real[key + "_u8"])[None]
         B, _, H, W = img.shape
@@ -460,12 +460,12 @@ def test_trispace_backward_vs_oracle_autograd(ops, dev, nc, residual_only, shape
 
 
 @pytest.mark.parametrize("residual_only", [False, True])
-def test_trispace_backward_on_8bit_content(ops, dev, residual_only):
+def test_trispace_backward_on_8bit_content(ops, dev, residual_only, golden):
     """tests/test_poly.py's statement on the device: the polynomial path's coefficient gradient on a whole photograph of the
     reference (bytes / 255: exact ties, the pixels generate_image's clamp pins) with black, white, grey and primary pixels
     written into it, against autograd through the oracle in FLOAT64."""
     import curl_oracle as O
-    real = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real8.npz"))
+    real = golden("real8")
     u8 = real["crop_u8"].copy()
     u8[0, :6] = [[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255]]
     img = O.u8hwc_to_f32chw(u8)[None].repeat(2, 1, 1, 1)

@@ -134,11 +134,11 @@ def test_twin_trispace_backward_column_strips(twin, residual_only):
 
 
 @pytest.mark.parametrize("residual_only", [False, True])
-def test_twin_trispace_backward_on_8bit_content(twin, residual_only):
+def test_twin_trispace_backward_on_8bit_content(twin, residual_only, golden):
     """The same on what the path is fed in production (infer.py:35-40: bytes / 255): a piece of the reference's own photograph
     with black, white, grey and primary pixels written into it -- exact ties, exact zeros, generate_image's clamp at work --
     against autograd through the oracle in FLOAT64."""
-    real = np.load(os.path.join(ROOT, "tests", "golden", "real8.npz"))
+    real = golden("real8")
     u8 = real["crop_u8"][100:112, 60:84].copy()
     u8[0, :6] = [[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255]]
     img = O.u8hwc_to_f32chw(u8)[None].repeat(2, 1, 1, 1)
