@@ -479,7 +479,13 @@ def cpu_baseline():
     Hk = torch.randn(32, 64, generator=g) * 0.1
     ones = torch.ones(32, 1, H_IMG, W_IMG)
     # the 1-GPU box gives this job a 16-cpu share of a 256-cpu host: more threads than that only thrash
-    threads = max(1, min(torch.get_num_threads(), int(os.environ.get("CURL_CPU_THREADS", 16))))
+    # (the cpus this process may run on, not torch.get_num_threads(): a launcher such as torch.distributed.run exports
+    # OMP_NUM_THREADS=1, which is a default for the ranks' GPU work, not a statement about the host)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("CURL_CPU_THREADS", 16))))
 
     def timed(fn, reps):
         ts = []

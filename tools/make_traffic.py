@@ -85,7 +85,13 @@ def main(tag):
         if workload in FRAG_KEYS and len(ks) >= 1:
             res[FRAG_KEYS[workload]] = dict(ks[0])
     os.makedirs("profiles", exist_ok=True)
-    json.dump(res, open(os.path.join("profiles", f"traffic_{tag}.json"), "w"), indent=1)
+    out_path = os.path.join("profiles", f"traffic_{tag}.json")
+    if os.path.exists(out_path):  # passes taken in several sessions (a GPU call hands back 64 MiB at most): new entries replace old ones
+        try:
+            res = {**json.load(open(out_path)), **res}
+        except Exception:
+            pass
+    json.dump(res, open(out_path, "w"), indent=1)
     for w, e in res.items():
         if "kernels" in e:
             print(f"{w:16s} {e['hbm_bytes_per_launch'] / 1e9:8.4f} GB per call, {e['us_per_call_trace_pass']:8.1f} us, "

@@ -12,3 +12,11 @@ for w in "$@"; do
   python3 tools/kstats.py gpurun_out/prof_${TAG}_$w/trace | head -6
 done
 python3 tools/make_traffic.py $TAG
+# SUMMARISE=1 (a GPU call hands back at most 64 MiB of gpurun_out/, one workload's four passes are 12 MiB): file the summaries
+# on the box (tools/file_profiles.py -> profiles/<tag>/, profiles/traffic_<tag>.json), hand THOSE back under
+# gpurun_out/filed_<tag>/ and drop the raw passes
+if [ "${SUMMARISE:-0}" = 1 ]; then
+  python3 tools/file_profiles.py $TAG "$@" || exit 1
+  mkdir -p gpurun_out/filed_$TAG && cp -r profiles/$TAG/. gpurun_out/filed_$TAG/ && cp profiles/traffic_$TAG.json gpurun_out/filed_$TAG/
+  rm -rf gpurun_out/prof_${TAG}_*
+fi
