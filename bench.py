@@ -780,11 +780,13 @@ def main():
             # >= 200 timed launches (>= 40 ms) each: the Lab-stage figure the 70 % target is quoted on rides here
             others[name] = measure(name, max(200, args.steps // 2), max(3, args.warmup // 2))
 
-    train = None
-    if not args.no_extras and os.environ.get("CURL_BENCH_TRAIN_STEP", "1") != "0":
+    def run_train_step():
         # Every rank takes part (DDP's all-reduce), so a failure on ONE rank must not leave the others waiting in a
         # collective: the ranks first agree (one MIN all-reduce) that each of them could build the model and run a step
         # alone; only then does the data-parallel measurement start.  Context only, never at the expense of the line.
+        if args.no_extras or os.environ.get("CURL_BENCH_TRAIN_STEP", "1") == "0":
+            return None
+        train = None
         try:
             ok = 1.0
             try:
@@ -801,10 +803,16 @@ def main():
                 train = {"error": "skipped: another rank failed the preflight"}
         except Exception as e:
             train = {"error": repr(e)}
+        return train
 
+    # N = 1: the train step is measured first and its three scalars ride in the line.  N > 1: THE LINE GOES OUT FIRST -- the
+    # data-parallel train step is the one part of this program that needs every rank to answer a collective, and a rank
+    # lost in it must not cost the scaling run its headline; its record goes to bench_detail.json / stderr afterwards.
+    train = run_train_step() if world == 1 else None
+    meta = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "batch_per_gpu": B, "backend": backend,
+            "ranks_seen": world if dist is None else dist.get_world_size(), "gpus_visible": n_dev}
+    detail = None
     if rank == 0:
-        meta = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "batch_per_gpu": B, "backend": backend,
-                "ranks_seen": world if dist is None else dist.get_world_size(), "gpus_visible": n_dev}
         accuracy = end = cpu = None
         if not args.no_extras:
             accuracy = accuracy_vs_oracle(ops, device)
@@ -813,14 +821,22 @@ def main():
                     end = end_to_end(ops, device, sets, masks)
                 except Exception as e:  # context only: never at the expense of the line
                     end = {"error": repr(e)}
-            # rank 0's host cores, after every timed region (the other ranks wait at the closing barrier)
+            # rank 0's host cores, after every timed region (the other ranks wait at the next collective)
             cpu = cpu_baseline()
         line = make_line(main_res, others, accuracy, cpu, meta, train)
         detail = {"line": line, "headline": main_res, "other_workloads": others, "accuracy": accuracy,
                   "end_to_end": end, "train_step": train, "cpu_baseline": cpu, "meta": meta}
-        write_detail(detail)
         print(dump_line(line))
         sys.stdout.flush()
+    if world > 1:
+        # (nothing may follow the line on stdout: whatever a library prints from here on goes to stderr)
+        sys.stdout.flush()
+        os.dup2(2, 1)
+        train = run_train_step()
+        if detail is not None:
+            detail["train_step"] = train
+    if detail is not None:
+        write_detail(detail)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
