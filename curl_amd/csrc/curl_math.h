@@ -711,24 +711,48 @@ CURL_HD Px adjust_hsv4(Px p, Affine k0, Affine k1, Affine k2, Affine k3) {
 
 // Per-curve host/prep arithmetic: slopes in float32 as the reference forms them (curves.py:19), every
 // sum in float64, one rounding at the end.  reg = sum of squared slope differences (curves.py:24).
-CURL_HD void collapse_curve(const float* C, int K, float& a, float& b, float& reg) {
-  double sum_s = 0.0, sum_js = 0.0, r = 0.0;
-  float prev = 0.0f;
-  for (int j = 0; j + 1 < K; ++j) {
-    float sl = C[j + 1] - C[j];
-    if (j + 2 < K) {  // slopes 0..K-3 reach the pixels (curves.py:31: slope[:, :-1])
-      sum_s += (double)sl;
-      sum_js += (double)j * (double)sl;
+// The sums are taken in ONE fixed order everywhere -- sixteen interleaved partial sums (partial l takes the terms j = l,
+// l + 16, ...), combined pairwise (l with l ^ 8, ^ 4, ^ 2, ^ 1) -- because that is the order sixteen lanes of a wavefront
+// produce (knots_prep_kernel and the in-kernel collapse give a curve 16 lanes: the K-long chain of dependent float64
+// operations one thread ran was a third of the ~3.4 us prologue a one-frame forward paid, round 5); collapse_curve is the
+// same arithmetic by one thread (the chain kernels, the host twin): identical bits.
+constexpr int kCollapseLanes = 16;
+struct CollapseSums {
+  double s, js, r;  // sum slope_j, sum j * slope_j (j <= K-3: curves.py:31 slope[:, :-1]); sum (slope_j - slope_{j-1})^2
+};
+CURL_HD CollapseSums collapse_partial(const float* C, int K, int l) {
+  CollapseSums p{0.0, 0.0, 0.0};
+  for (int j = l; j + 1 < K; j += kCollapseLanes) {
+    const float cj = C[j], sl = C[j + 1] - cj;
+    if (j + 2 < K) {
+      p.s += (double)sl;
+      p.js += (double)j * (double)sl;
     }
     if (j > 0) {
-      float d = sl - prev;
-      r += (double)(d * d);
+      const float d = sl - (cj - C[j - 1]);
+      p.r += (double)(d * d);
     }
-    prev = sl;
   }
-  a = (float)((double)C[0] - sum_js);
-  b = (float)((double)(K - 1) * sum_s);
-  reg = (float)r;
+  return p;
+}
+CURL_HD void collapse_finish(const float* C, int K, const CollapseSums& t, float& a, float& b, float& reg) {
+  a = (float)((double)C[0] - t.js);
+  b = (float)((double)(K - 1) * t.s);
+  reg = (float)t.r;
+}
+// what lane l holds after the steps that trade with lane l ^ 8, ..., l ^ O (O = 16: the lane's own partial sums): the value
+// of S(l, O) = S(l, 2 O) + S(l ^ O, 2 O), by recursion instead of sixteen live partials (five are alive at a time)
+template <int O>
+CURL_HD CollapseSums collapse_tree(const float* C, int K, int l) {
+  if constexpr (O == kCollapseLanes) {
+    return collapse_partial(C, K, l);
+  } else {
+    const CollapseSums x = collapse_tree<2 * O>(C, K, l), y = collapse_tree<2 * O>(C, K, l ^ O);
+    return CollapseSums{x.s + y.s, x.js + y.js, x.r + y.r};
+  }
+}
+CURL_HD void collapse_curve(const float* C, int K, float& a, float& b, float& reg) {
+  collapse_finish(C, K, collapse_tree<1>(C, K, 0), a, b, reg);
 }
 
 // curves.py:31-32 in torch's evaluation order: t_j = slope_j * (S*x - j) rounded term by term, summed
