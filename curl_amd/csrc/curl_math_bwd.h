@@ -496,6 +496,25 @@ CURL_HD float knot_bwd(const float* C, int K, double P, double Q, double g_reg, 
   if (kk == 0) gC += P;  // the C0 term of the scale
   return (float)(gC * (double)C[kk]);  // d exp(raw) = C
 }
+// The same from the five knots around kk held in registers (c[d] = C[kk - 2 + d]; entries outside the curve are never used:
+// the conditions below are knot_bwd's): knots_bwd_kernel asks for them at its very top, long before P and Q exist, so that no
+// memory latency is left behind its reductions.  Operation for operation knot_bwd: identical bits.
+CURL_HD float knot_bwd5(const float (&c)[5], int K, double P, double Q, double g_reg, int kk) {
+  const double S = (double)(K - 1);
+  // slope differences as knot_bwd's sl(i) = (double)(C[i + 1] - C[i]) for i = kk - 2 .. kk + 1
+  const double sl_m2 = (double)(c[1] - c[0]), sl_m1 = (double)(c[2] - c[1]), sl_0 = (double)(c[3] - c[2]), sl_p1 = (double)(c[4] - c[3]);
+  auto dslope = [&](int j, double sl_j, double sl_jm1, double sl_jp1) -> double {
+    if (j < 0 || j > K - 2) return 0.0;
+    double v = 0.0;
+    if (j <= K - 3) v += S * Q - (double)j * P;
+    if (j >= 1) v += g_reg * 2.0 * (sl_j - sl_jm1);
+    if (j + 1 <= K - 2) v -= g_reg * 2.0 * (sl_jp1 - sl_j);
+    return v;
+  };
+  double gC = dslope(kk - 1, sl_m1, sl_m2, sl_0) - dslope(kk, sl_0, sl_m1, sl_p1);
+  if (kk == 0) gC += P;
+  return (float)(gC * (double)c[2]);
+}
 CURL_HD void knots_bwd(const float* C, int K, double P, double Q, double g_reg, float* g_raw) {
   for (int kk = 0; kk < K; ++kk) g_raw[kk] = knot_bwd(C, K, P, Q, g_reg, kk);
 }
