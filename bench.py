@@ -832,14 +832,40 @@ def main():
         # (nothing may follow the line on stdout: whatever a library prints from here on goes to stderr)
         sys.stdout.flush()
         os.dup2(2, 1)
+        # ... and nothing may keep the scaling run from ending: the headline is out; if the data-parallel step (MIOpen's solver
+        # search, DDP's bucket all-reduces over RCCL) has not come back in CURL_BENCH_TRAIN_TIMEOUT seconds, every rank's own
+        # watchdog ends its process with the code of a finished run.
+        import threading
+        limit = float(os.environ.get("CURL_BENCH_TRAIN_TIMEOUT", 240))
+
+        def give_up():
+            sys.stderr.write(f"bench.py: rank {rank}: the data-parallel train step did not finish in {limit:.0f} s; the line is "
+                             "out, ending the run without its record\n")
+            sys.stderr.flush()
+            if detail is not None:
+                detail["train_step"] = {"error": f"timed out after {limit:.0f} s"}
+                try:
+                    write_detail(detail)
+                except Exception:
+                    pass
+            os._exit(0)
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
         train = run_train_step()
+        dog.cancel()
         if detail is not None:
             detail["train_step"] = train
     if detail is not None:
         write_detail(detail)
     if dist is not None:
+        import threading
+        dog2 = threading.Timer(120.0, lambda: os._exit(0))  # (a rank that never arrives must not hold the others' exit)
+        dog2.daemon = True
+        dog2.start()
         dist.barrier()
         dist.destroy_process_group()
+        dog2.cancel()
 
 
 if __name__ == "__main__":

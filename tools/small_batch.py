@@ -112,8 +112,22 @@ for (B, H, W) in ((1, 1000, 1500), (2, 1000, 1500), (4, 1000, 1500), (32, 256, 2
                                     scratch.data_ptr(), sb, B, H, W, 16, 16, 16, _lib.F_WS_READY | args.flags_bwd, stream)
         assert rc == 0, lib.curl_last_error()
 
+    # the live model's per-pixel path between bytes (infer.py:35-47: ONE image per call): curl_trispace_fwd_u8hwc
+    u8s = [(im * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() for im in imgs]
+    coeffs = torch.randn(B, 3, 3, 126, device=dev) * 0.2
+    out8 = torch.empty_like(u8s[0])
+
+    def tri_py():
+        cnt[0] += 1
+        return ops.trispace_forward_u8hwc(u8s[cnt[0] & 1], coeffs)
+
+    def tri_c():
+        cnt[0] += 1
+        rc = lib.curl_trispace_fwd_u8hwc(u8s[cnt[0] & 1].data_ptr(), coeffs.data_ptr(), 0, out8.data_ptr(), B, H, W, 126, 0, stream)
+        assert rc == 0, lib.curl_last_error()
+
     n = args.n if B * H * W < 16e6 else 100
-    for name, py, c in (("fwd", fwd_py, fwd_c), ("bwd", bwd_py, bwd_c), ("bwdk", bwdk_py, bwdk_c)):
+    for name, py, c in (("fwd", fwd_py, fwd_c), ("bwd", bwd_py, bwd_c), ("bwdk", bwdk_py, bwdk_c), ("tri8", tri_py, tri_c)):
         w, h = window(py, n)
         wc, hc = window(c, n)
         lat = latency(c)
