@@ -106,11 +106,17 @@ WORKLOADS = {
                      mask="ones", bound="valu", flop_px=241.2),
     "loss_bwd": dict(desc="CURLLoss pointwise terms backward (gradient w.r.t. the prediction)", bpp=41.0,
                      frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=356.0),
+    "train_fwd": dict(desc="the train step's forward in ONE pass (curl_layer_loss_fwd_f32, main.py:283-285: CURLLayer.forward + "
+                           "CURLLoss' pointwise terms on the prediction in registers; out, reg, 5 sums, both L planes), bool mask all "
+                           "ones", bpp=45.0, frag="layer_loss_kernel", mask="ones", bound="valu", flop_px=439.2),
+    "train_fwd_two_calls": dict(desc="the same as two calls (curl_layer_fwd_f32 then curl_loss_terms_f32: 25 + 33 B/px)", bpp=58.0,
+                                frag="loss_terms_kernel", mask="ones", bound="valu", flop_px=439.2),
     "trispace_bwd": dict(desc="polynomial path backward (curl_trispace_bwd_f32: d loss / d 3x3x126 coefficients, main.py:287) "
                               "on 8 x 1500x1000 frames: three kernels, 72 B/px of intermediates between the first two",
                          bpp=24.0, frag="trispace_bwd", mask=None, bound="valu", flop_px=3059.0, images=8),
 }
-CONFIG5 = ("layer_bwd", "layer_bwd_crop", "layer_bwd_knots", "layer_bwd_crop_knots", "loss_fwd", "loss_bwd", "trispace_bwd")
+CONFIG5 = ("layer_bwd", "layer_bwd_crop", "layer_bwd_knots", "layer_bwd_crop_knots", "loss_fwd", "loss_bwd", "trispace_bwd", "train_fwd",
+           "train_fwd_two_calls")
 
 
 def workload_pixels(name, B):
@@ -156,6 +162,14 @@ def make_step(name, ops, masks, sets=None):
         if name == "trispace_bwd":
             return lambda s: ops.trispace_backward(s[0][:n], s[4][:n], gouts[ids[id(s)]])
         other = sets[1 % len(sets)][0]
+        if name == "train_fwd":
+            return lambda s: ops.layer_loss_forward(s[0], mask, s[1], s[2], s[3], other)
+
+        if name == "train_fwd_two_calls":
+            def two(s):
+                out, reg = ops.curl_layer_forward(s[0], mask, s[1], s[2], s[3])
+                return ops.loss_term_sums(out, other, mask)
+            return two
         if name == "loss_fwd":
             return lambda s: ops.loss_term_sums(s[0], other, mask)
         w4 = torch.ones(4, device=other.device)

@@ -72,6 +72,8 @@ SIGNATURES = {
     "curl_loss_terms_scratch_bytes": (_sz, [_i, _i, _i]),
     "curl_loss_terms_f32": (_i, [_c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _sz, _i, _i, _i, _c_f]),
     "curl_loss_terms_bwd_f32": (_i, [_c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _i, _i, _i, _c_f]),
+    "curl_layer_loss_fwd_f32": (_i, [_c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _c_f, _sz,
+                                     _i, _i, _i, _i, _i, _i, _u, _c_f]),
     "curl_compose_white_u8hwc": (_i, [_c_f, _c_f, _i, _c_f, _i, _i, _i, _c_f]),
 }
 

@@ -275,12 +275,21 @@ class GCURLNet(nn.Module):
                                           align_corners=False, antialias=True)
         return self.backbone(x)  # model.py:196
 
-    def forward(self, img, mask, L=None, R=None, H=None):
-        """L, R, H are accepted and ignored, exactly as in the reference (model.py:195-199 overwrites them)."""
+    def forward(self, img, mask, L=None, R=None, H=None, target=None, criterion=None):
+        """L, R, H are accepted and ignored, exactly as in the reference (model.py:195-199 overwrites them).
+        target / criterion (not in the reference): given a target image and a CURLLoss, the training step's two calls
+        (main.py:283-285) run with the layer and the loss' pointwise terms as ONE forward kernel (_LayerLossFn) and the
+        result is (img, gradient_regulariser, loss) -- the values and gradients of `criterion(self(img, mask)[0], target, mask)`."""
         curves = self.predict_knots(img)
         L, R, H = curves[:, :self.curve_break_1], \
             curves[:, self.curve_break_1:self.curve_break_2], \
             curves[:, self.curve_break_2:]
+        if target is not None:
+            lay = self.curllayer
+            L, R, H = L[:, :lay.num_lab_points], R[:, :lay.num_rgb_points], H[:, :lay.num_hsv_points]  # model.py:153,159,165
+            out, reg, rgb, cosine, lab, hsv, Lp, Lt = _LayerLossFn.apply(img, mask, L, R, H, target)
+            ssim = (1.0 - criterion.msssim_layer(Lp, Lt)).mean() if criterion.msssim_layer is not None else 0.0
+            return out, reg, (rgb + cosine + lab + hsv + 10 * ssim) / 5  # model.py:111-116
         img, gradient_regulariser = self.curllayer(img, mask, L, R, H)
         return img, gradient_regulariser
 
@@ -511,6 +520,62 @@ class _LossTermsFn(torch.autograd.Function):
         w = torch.stack((g_rgb.double() / unmasked, -g_cos.double() / ctx.n, g_lab.double() / unmasked,
                          g_hsv.double() / unmasked)).to(torch.float32)
         return ops.loss_terms_backward(pred, target, ctx.mask, w, g_Lp), None, None
+
+
+class _LayerLossFn(torch.autograd.Function):
+    """(img, mask, L, R, H, target) -> (out, reg, rgb_l1, cosine, lab_l1, hsv_l1, L_pred, L_target): CURLLayer.forward and
+    CURLLoss' pointwise terms in ONE forward pass (ops.layer_loss_forward); the backward is the two existing kernels in
+    sequence -- the loss terms' pullback to the prediction, added to whatever gradient `out` received itself, then the
+    layer's backward with the forward's knot workspace."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, img, mask, L, R, H, target):
+        out, reg, sums, Lp, Lt, ws = ops.layer_loss_forward(img, mask, L, R, H, target)
+        s = sums.sum(0)
+        n = float(out.shape[0] * out.shape[2] * out.shape[3])
+        rep = 1 if mask is None else out.shape[0] // mask.shape[0]  # a one-image mask broadcast over the batch: _LossTermsFn
+        unmasked = 3.0 * s[4] / rep
+        rgb, lab, hsv = s[0] / unmasked, s[2] / unmasked, s[3] / unmasked
+        n_zero = (mask == 0).sum().double() * rep if (mask is not None and mask.is_floating_point()) else n - s[4]
+        cosine = 1.0 - s[1] / n - n_zero / n  # model.py:98 (see _LossTermsFn)
+        ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous(), ws, out, target, unmasked)
+        ctx.mask, ctx.n = mask, n
+        ctx.mark_non_differentiable(Lt)
+        f = torch.float32
+        return out, reg, rgb.to(f), cosine.to(f), lab.to(f), hsv.to(f), Lp, Lt
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_out, g_reg, g_rgb, g_cos, g_lab, g_hsv, g_Lp, _g_Lt):
+        img, L, R, H, ws, out, target, unmasked = ctx.saved_tensors
+        w = torch.stack((g_rgb.double() / unmasked, -g_cos.double() / ctx.n, g_lab.double() / unmasked,
+                         g_hsv.double() / unmasked)).to(torch.float32)
+        g_pred = ops.loss_terms_backward(out, target, ctx.mask, w, g_Lp)
+        if g_out is not None:
+            g_pred = g_pred + g_out
+        g_img, gL, gR, gH = ops.curl_layer_backward(img, ctx.mask, L, R, H, g_pred, g_reg, ctx.needs_input_grad[0], workspace=ws)
+        return g_img, None, gL, gR, gH, None
+
+
+class CURLLayerWithLoss(nn.Module):
+    """Not in the reference: its training step's two calls -- `net_output_img = net(...)` and `criterion(net_output_img, gt,
+    mask)` (main.py:283-285) -- as one module, so that the layer and the loss' pointwise terms run as ONE forward kernel.
+    forward(img, mask, L, R, H, target) -> (out, reg, loss) with `loss` = CURLLoss()(out, target, mask) and `out`, `reg` =
+    CURLLayer()(img, mask, L, R, H): the same values (tests/test_gpu_backward.py), the same gradients.  The MS-SSIM term is
+    the reference's layer on the two L planes, as in CURLLoss."""
+
+    def __init__(self, num_lab_points=48, num_rgb_points=48, num_hsv_points=64, ssim_window_size=5, num_channel=1,
+                 msssim_layer="reference"):
+        super().__init__()
+        self.num_lab_points, self.num_rgb_points, self.num_hsv_points = num_lab_points, num_rgb_points, num_hsv_points
+        self.msssim_layer = metric.MSSSIMMetric(num_channel=num_channel) if msssim_layer == "reference" else msssim_layer
+
+    def forward(self, img, mask, L, R, H, target):
+        L, R, H = L[:, :self.num_lab_points], R[:, :self.num_rgb_points], H[:, :self.num_hsv_points]  # model.py:153,159,165
+        out, reg, rgb, cosine, lab, hsv, Lp, Lt = _LayerLossFn.apply(img, mask, L, R, H, target)
+        ssim = (1.0 - self.msssim_layer(Lp, Lt)).mean() if self.msssim_layer is not None else 0.0
+        return out, reg, (rgb + cosine + lab + hsv + 10 * ssim) / 5  # model.py:111-116
 
 
 class CURLLoss(nn.Module):

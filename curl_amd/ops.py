@@ -723,6 +723,36 @@ def loss_term_sums(pred, target, mask, want_L=True):
 
 
 @_one_device
+def layer_loss_forward(img, mask, L, R, H, target, want_L=True):
+    """The train step's forward in one pass (main.py:283-285): CURLLayer.forward (model.py:137-176) and CURLLoss' pointwise
+    terms (model.py:89-109) on the prediction while it is in registers -- curl_layer_loss_fwd_f32.
+    -> (out, reg[B], sums [B,5] float64, L_pred, L_target, workspace): what curl_layer_forward(..., return_workspace=True) and
+    loss_term_sums(out, target, mask) return, the same bits, with one mask for both."""
+    lib = _lib.load()
+    img, target = _image(img), _image(target, "target")
+    if img.shape != target.shape:
+        raise ValueError("img and target must have the same shape")
+    B, _, Hh, W = img.shape
+    Lc, Kl = _knots(L, "L", 3, B)
+    Rc, Kr = _knots(R, "R", 3, B)
+    Hc, Kh = _knots(H, "H", 4, B)
+    m, kind = _mask(mask, img)
+    out = torch.empty_like(img)
+    reg = torch.empty(B, dtype=torch.float32, device=img.device)
+    sums = torch.empty(B, 5, dtype=torch.float64, device=img.device)
+    Lp = torch.empty(B, 1, Hh, W, dtype=torch.float32, device=img.device) if want_L else None
+    Lt = torch.empty_like(Lp) if want_L else None
+    ws, nbytes = _workspace(B, Lc.shape[1] + Rc.shape[1] + Hc.shape[1], img.device)
+    sbytes = lib.curl_loss_terms_scratch_bytes(B, Hh, W)
+    scratch = torch.empty(sbytes // 4, dtype=torch.float32, device=img.device)
+    rc = lib.curl_layer_loss_fwd_f32(img.data_ptr(), _ptr(m), kind, Lc.data_ptr(), Rc.data_ptr(), Hc.data_ptr(), target.data_ptr(),
+                                     out.data_ptr(), reg.data_ptr(), sums.data_ptr(), _ptr(Lp), _ptr(Lt), ws.data_ptr(), nbytes,
+                                     scratch.data_ptr(), sbytes, B, Hh, W, Kl, Kr, Kh, 0, _stream(img))
+    _lib.check(rc, "curl_layer_loss_fwd_f32")
+    return out, reg, sums, Lp, Lt, ws
+
+
+@_one_device
 def loss_terms_backward(pred, target, mask, weights, grad_L_pred=None):
     """d(sum_k weights[k] * sum_k-th pointwise sum + <grad_L_pred, L_pred>) / d pred.  weights: device float32 [4]."""
     lib = _lib.load()

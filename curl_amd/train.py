@@ -100,6 +100,9 @@ def main(argv=None):
     ap.add_argument("--foreground_masks", action="store_true",
                     help="--arch curl: the masks have sizeable empty regions (data.py:186-190) -- masked-out wavefronts skip "
                          "their pixel loads (CURL_F_MASK_FIRST; same results)")
+    ap.add_argument("--fused_forward", action="store_true",
+                    help="--arch curl: the layer and CURLLoss' pointwise terms as ONE forward kernel (curl_layer_loss_fwd_f32); the "
+                         "same loss and gradients as main.py:283-285's two calls")
     ap.add_argument("--save_images", action="store_true", help="dump validation outputs under --log_dirpath (evaluate.py:49-66)")
     ap.add_argument("--amp", choices=("off", "bf16"), default="off",
                     help="bf16: torch.autocast around the encoder (stock PyTorch-ROCm); the per-pixel HIP kernels and "
@@ -167,6 +170,8 @@ def main(argv=None):
     if ddp:
         net = nn.parallel.DistributedDataParallel(net, device_ids=[device.index], output_device=device.index)  # main.py:225
     criterion = model.CURLLoss(ssim_window_size=5).to(device)                 # main.py:228
+    if args.fused_forward and args.arch != "curl":
+        raise SystemExit("--fused_forward is the curve model's (--arch curl)")
     validation_evaluator = evaluate.Evaluator(criterion, valid_loader, "valid", args.log_dirpath, local_rank=rank)  # main.py:233
     optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, net.parameters()), lr=5e-7, betas=(0.5, 0.999))
     scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=1e-4, total_steps=args.num_epoch)
@@ -188,9 +193,14 @@ def main(argv=None):
         for batch in train_loader:
             t0 = time.perf_counter()
             img, gt, mask = (batch[k].to(device, non_blocking=True) for k in ("input_img", "output_img", "mask"))
-            with autocast():
-                out = forward_image(net, img, mask)                           # main.py:283
-            loss = criterion(out.float(), gt, mask)                           # main.py:285
+            if args.fused_forward:
+                # the curve model's layer and the loss' pointwise terms as ONE forward kernel (curl_layer_loss_fwd_f32)
+                with autocast():
+                    out, _reg, loss = net(img, mask, target=gt, criterion=criterion)
+            else:
+                with autocast():
+                    out = forward_image(net, img, mask)                       # main.py:283
+                loss = criterion(out.float(), gt, mask)                       # main.py:285
             optimizer.zero_grad()
             loss.backward()                                                   # main.py:287
             optimizer.step()

@@ -316,6 +316,22 @@ int curl_loss_terms_bwd_f32(const float* pred, const float* target, const void* 
                             const float* weights, const float* grad_L_pred, float* grad_pred,
                             int B, int H, int W, curl_stream_t stream);
 
+/* replaces: the forward half of a training step of the curve model -- `net_output = net(input, mask)` then
+ *           `loss = criterion(net_output, gt, mask)` (main.py:283-285), i.e. CURLLayer.forward (model.py:137-176) followed by
+ *           CURLLoss.forward's pointwise terms (model.py:89-109) -- as ONE pass over the pixels: the loss terms are taken on
+ *           the prediction while it is in registers (no 12 B/px round trip, no second read of the mask, one launch less;
+ *           launches of <= 2 048 workgroups also collapse their curves inside the kernel).
+ * Outputs are those of curl_layer_fwd_f32 (out, reg, the workspace row -- hand it to curl_layer_bwd_f32 with
+ * CURL_F_WS_READY) and of curl_loss_terms_f32 (sums [B,5] float64, L_pred / L_target [B,1,H,W], nullable), the same
+ * bits as the two calls give.  mask / mask_kind: ONE mask for both (main.py passes the same tensor twice).
+ * workspace: curl_workspace_bytes(B, 3*Kl+3*Kr+4*Kh); scratch: curl_loss_terms_scratch_bytes(B,H,W).  flags: 0. */
+int curl_layer_loss_fwd_f32(const float* img, const void* mask, int mask_kind,
+                            const float* rawL, const float* rawR, const float* rawH, const float* target,
+                            float* out, float* reg, double* sums, float* L_pred, float* L_target,
+                            void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                            int B, int H, int W, int Kl, int Kr, int Kh, unsigned flags, curl_stream_t stream);
+
+
 #ifdef __cplusplus
 }
 #endif

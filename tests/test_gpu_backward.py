@@ -918,3 +918,88 @@ def test_backward_refuses_a_workspace_nobody_filled(ops, dev):
     big[:ws8.numel()] = ws8
     bad = ops.curl_layer_backward(img, None, L, R, Hk, gout, workspace=big)
     assert all(torch.isnan(t).all() for t in bad) 
+
+@pytest.mark.parametrize("shape,mask_kind", [((3, 40, 56), "bool"), ((2, 37, 53), "bool"), ((2, 40, 56), "f32"), ((2, 40, 56), "none"),
+                                             ((2, 96, 128), "broadcast_bool")])
+def test_layer_and_loss_terms_in_one_forward_pass(dev, shape, mask_kind):
+    """curl_layer_loss_fwd_f32 (the train step's forward as one kernel: main.py:283-285): `out`, `reg`, the five sums, both L
+    planes and the workspace row are the bits of curl_layer_fwd_f32 followed by curl_loss_terms_f32 -- the float4 path, the
+    scalar path (37x53), every mask kind, the in-kernel curve collapse (these sizes) -- and against the oracle."""
+    import curl_oracle as O
+    from curl_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(31)
+    img, tgt = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    L, R, Hk = (torch.randn(B, n, generator=g) * 0.1 for n in (48, 48, 64))
+    mb = torch.rand(B, 1, H, W, generator=g) > 0.25
+    mask = {"bool": mb, "f32": mb.float() * 0.8, "none": None, "broadcast_bool": mb[:1]}[mask_kind]
+    md = None if mask is None else mask.to(dev)
+    out, reg, sums, Lp, Lt, ws = ops.layer_loss_forward(img.to(dev), md, L.to(dev), R.to(dev), Hk.to(dev), tgt.to(dev))
+    out2, reg2, ws2 = ops.curl_layer_forward(img.to(dev), md, L.to(dev), R.to(dev), Hk.to(dev), return_workspace=True)
+    sums2, Lp2, Lt2 = ops.loss_term_sums(out2, tgt.to(dev), md)
+    assert torch.equal(out, out2) and torch.equal(reg, reg2)
+    assert torch.equal(Lp, Lp2) and torch.equal(Lt, Lt2)
+    assert torch.equal(sums, sums2), (sums - sums2).abs().max()
+    a, b = ws.view(torch.int32).view(B, -1), ws2.view(torch.int32).view(B, -1)
+    assert all(torch.equal(a[:, sl], b[:, sl]) for sl in (slice(0, 24), slice(29, 30), slice(32, 192)))
+    # the workspace it filled serves the backward as the layer's own does
+    gout = torch.rand(B, 3, H, W, generator=g).to(dev)
+    g1 = ops.curl_layer_backward(img.to(dev), md, L.to(dev), R.to(dev), Hk.to(dev), gout, workspace=ws)
+    g2 = ops.curl_layer_backward(img.to(dev), md, L.to(dev), R.to(dev), Hk.to(dev), gout, workspace=ws2)
+    assert all(torch.equal(x, y) for x, y in zip(g1, g2))
+    # and the oracle
+    mo = torch.ones(B, 1, H, W) if mask is None else mask.float().expand(B, 1, H, W)
+    ref, _ = O.curl_layer(img, mo, L, R, Hk)
+    assert float((out.cpu() - ref).abs().max()) <= 1e-4
+
+
+def test_layer_with_loss_module_equals_the_two_modules(dev):
+    """model.CURLLayerWithLoss (one forward kernel) against model.CURLLayer + model.CURLLoss (two): the same loss, the same
+    output, the same gradients w.r.t. the knots and the image -- with a stand-in for MS-SSIM that uses both L planes."""
+    from curl_amd import model
+    g = torch.Generator().manual_seed(32)
+    B, H, W = 3, 48, 64
+    img, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.2).to(dev)
+    fake_ssim = lambda a, b: 1.0 - (a - b).abs().mean(dim=(1, 2, 3))  # noqa: E731
+    grads = []
+    for fused in (True, False):
+        L, R, Hk = ((torch.randn(B, n, generator=torch.Generator().manual_seed(5 + n)) * 0.1).to(dev).requires_grad_(True) for n in (48, 48, 64))
+        x = img.clone().requires_grad_(True)
+        if fused:
+            out, reg, loss = model.CURLLayerWithLoss(msssim_layer=fake_ssim)(x, mask, L, R, Hk, tgt)
+        else:
+            out, reg = model.CURLLayer()(x, mask, L, R, Hk)
+            loss = model.CURLLoss(msssim_layer=fake_ssim)(out, tgt, mask)
+        total = loss + 1e-6 * reg.mean() + 1e-3 * out.mean()  # `out` is used downstream too (its own gradient adds)
+        total.backward()
+        grads.append((float(loss.detach()), out.detach(), x.grad, L.grad, R.grad, Hk.grad))
+    assert grads[0][0] == grads[1][0] and torch.equal(grads[0][1], grads[1][1])
+    for a, b in zip(grads[0][2:], grads[1][2:]):
+        assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+
+def test_gcurlnet_fused_train_forward_equals_the_two_calls(dev):
+    """GCURLNet(img, mask, target=gt, criterion=CURLLoss) -- the train step with one forward kernel for the layer and the loss'
+    pointwise terms (curl_amd.train --fused_forward) -- against criterion(net(img, mask)[0], gt, mask): loss, output and every
+    parameter gradient of the encoder's head."""
+    from curl_amd import model
+    torch.manual_seed(11)
+    net = model.GCURLNet(backbone=model.CurveEncoder(num_outputs=160, width=0.25, num_features=256), encoder_size=64).to(dev).train()
+    crit = model.CURLLoss(msssim_layer=lambda a, b: 1.0 - (a - b).abs().mean(dim=(1, 2, 3))).to(dev)
+    g = torch.Generator().manual_seed(12)
+    img, gt = torch.rand(4, 3, 64, 64, generator=g).to(dev), torch.rand(4, 3, 64, 64, generator=g).to(dev)
+    mask = (torch.rand(4, 1, 64, 64, generator=g) > 0.2).to(dev)
+    res = []
+    for fused in (True, False):
+        net.zero_grad()
+        if fused:
+            out, reg, loss = net(img, mask, target=gt, criterion=crit)
+        else:
+            out, reg = net(img, mask)
+            loss = crit(out, gt, mask)
+        (loss + 1e-6 * reg.mean()).backward()
+        res.append((float(loss.detach()), out.detach().clone(), [p.grad.clone() for p in net.backbone.classifier.parameters()]))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())

@@ -22,7 +22,8 @@ FRAG = {"layer": "OpLayer", "layer_8bit": "OpLayer", "layer_disk": "OpLayer", "l
         "trispace_u8": "OpTriSpace", "lab_stage": "OpLabStage", "hsv_stage": "OpHsvStage", "rgb_only": "OpAdjust3",
         "trispace": "OpTriSpace", "layer_bwd": "layer_bwd_kernel", "layer_bwd_crop": "layer_bwd_kernel",
         "layer_bwd_knots": "layer_bwd_kernel", "layer_bwd_crop_knots": "layer_bwd_kernel",
-        "loss_fwd": "loss_terms_kernel", "loss_bwd": "loss_terms_bwd_kernel", "trispace_bwd": "trispace_coef_grad"}
+        "loss_fwd": "loss_terms_kernel", "loss_bwd": "loss_terms_bwd_kernel", "train_fwd": "layer_loss_kernel",
+        "train_fwd_two_calls": "loss_terms_kernel", "trispace_bwd": "trispace_coef_grad"}
 tag, workloads = sys.argv[1], sys.argv[2:]
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)

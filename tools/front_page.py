@@ -53,12 +53,17 @@ WORDS = {
                  "over the 8 colours of a lane", "46 880 workgroups", "§3b; `profiles/r04/loss_fwd_pmc_summary.json`"),
     "loss_bwd": ("`loss_terms_bwd_kernel` · `curl_loss_terms_bwd_f32`", "taped converters, `sign` as two scalings + median; round 5: without the identity "
                  "clamps / gates on RGB2HSV's output", "46 880 workgroups", "§3b, §3f.3; `profiles/r05/ab_loss_hsv_identity_clamps.log`"),
+    "train_fwd": ("`layer_loss_kernel` + `loss_terms_final_kernel` · `curl_layer_loss_fwd_f32`", "round 5: the train step's forward in one pass "
+                  "(main.py:283-285) -- the layer, then CURLLoss' pointwise terms on the prediction in registers; `out`, `reg`, sums and L planes "
+                  "are the two-call route's bits", "46 880 workgroups, 4 waves/SIMD (115 VGPRs); ≤ 2 048 workgroups collapse their curves inside",
+                  "§3f.7; `profiles/r05/ab_train_fwd.log`"),
+    "train_fwd_two_calls": ("`curl_layer_fwd_f32` then `curl_loss_terms_f32`", "the same work as two calls (25 + 33 B/px)", "as `layer` + `loss_fwd`", "§3f.7"),
     "trispace_bwd": ("`trispace_bwd_px` + `trispace_coef_grad` + `trispace_coef_final` · `curl_trispace_bwd_f32`",
                      "per-pixel pullback to 18 planes, then strip-tiled coefficient sums (72 B/px of intermediates; the one-pass form lost)",
                      "three launches; 8 × 1500×1000", "§3e.4; `profiles/r04/poly_bwd_fused_vs_three_kernel_ab.log`"),
 }
 ORDER = ["layer", "layer_8bit", "layer_disk", "layer_disk_mask_first", "lab_stage", "hsv_stage", "rgb_only", "layer_u8", "trispace",
-         "trispace_u8", "layer_bwd", "layer_bwd_knots", "layer_bwd_crop", "layer_bwd_crop_knots", "loss_fwd", "loss_bwd", "trispace_bwd"]
+         "trispace_u8", "layer_bwd", "layer_bwd_knots", "layer_bwd_crop", "layer_bwd_crop_knots", "loss_fwd", "loss_bwd", "train_fwd", "train_fwd_two_calls", "trispace_bwd"]
 
 
 def table(detail):

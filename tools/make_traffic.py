@@ -27,6 +27,8 @@ KERNELS = {
     "layer_bwd": ["layer_bwd_kernel", "knots_bwd_kernel"], "layer_bwd_crop": ["layer_bwd_kernel", "knots_bwd_kernel"],
     "layer_bwd_knots": ["layer_bwd_kernel", "knots_bwd_kernel"], "layer_bwd_crop_knots": ["layer_bwd_kernel", "knots_bwd_kernel"],
     "loss_fwd": ["loss_terms_kernel", "loss_terms_final_kernel"], "loss_bwd": ["loss_terms_bwd_kernel"],
+    "train_fwd": ["layer_loss_kernel", "loss_terms_final_kernel"],
+    "train_fwd_two_calls": ["OpLayer", "loss_terms_kernel", "loss_terms_final_kernel"],
     "trispace_bwd": ["trispace_bwd_px", "trispace_coef_grad", "trispace_coef_final", "trispace_bwd_fused"],
 }
 FRAG_KEYS = {"layer": "OpLayer", "lab_stage": "OpLabStage", "hsv_stage": "OpHsvStage", "rgb_only": "OpAdjust3",
