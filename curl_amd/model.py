@@ -285,7 +285,7 @@ class GCURLNet(nn.Module):
             curves[:, self.curve_break_1:self.curve_break_2], \
             curves[:, self.curve_break_2:]
         if target is not None:
-            lay = self.curllayer
+            lay = self.curllayer  # (its foreground_masks / paper_pwl options are the stand-alone layer's: not taken here)
             L, R, H = L[:, :lay.num_lab_points], R[:, :lay.num_rgb_points], H[:, :lay.num_hsv_points]  # model.py:153,159,165
             out, reg, rgb, cosine, lab, hsv, Lp, Lt = _LayerLossFn.apply(img, mask, L, R, H, target)
             ssim = (1.0 - criterion.msssim_layer(Lp, Lt)).mean() if criterion.msssim_layer is not None else 0.0
@@ -542,6 +542,7 @@ class _LayerLossFn(torch.autograd.Function):
         ctx.save_for_backward(img, L.contiguous(), R.contiguous(), H.contiguous(), ws, out, target, unmasked)
         ctx.mask, ctx.n = mask, n
         ctx.mark_non_differentiable(Lt)
+        ctx.set_materialize_grads(False)  # an output nobody used arrives as None, not as a zero image to be added
         f = torch.float32
         return out, reg, rgb.to(f), cosine.to(f), lab.to(f), hsv.to(f), Lp, Lt
 
@@ -549,8 +550,9 @@ class _LayerLossFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_out, g_reg, g_rgb, g_cos, g_lab, g_hsv, g_Lp, _g_Lt):
         img, L, R, H, ws, out, target, unmasked = ctx.saved_tensors
-        w = torch.stack((g_rgb.double() / unmasked, -g_cos.double() / ctx.n, g_lab.double() / unmasked,
-                         g_hsv.double() / unmasked)).to(torch.float32)
+        zero = torch.zeros((), dtype=torch.float64, device=out.device)
+        d = lambda g: zero if g is None else g.double()  # noqa: E731
+        w = torch.stack((d(g_rgb) / unmasked, -d(g_cos) / ctx.n, d(g_lab) / unmasked, d(g_hsv) / unmasked)).to(torch.float32)
         g_pred = ops.loss_terms_backward(out, target, ctx.mask, w, g_Lp)
         if g_out is not None:
             g_pred = g_pred + g_out

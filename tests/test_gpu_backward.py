@@ -1003,3 +1003,23 @@ def test_gcurlnet_fused_train_forward_equals_the_two_calls(dev):
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+
+def test_layer_with_loss_when_only_the_loss_is_used(dev):
+    """The usual training step uses the loss alone: `out` and `reg` receive no gradient (None, not a zero image to be added)."""
+    from curl_amd import model
+    g = torch.Generator().manual_seed(1)
+    img, tgt = torch.rand(2, 3, 32, 32, generator=g).to(dev), torch.rand(2, 3, 32, 32, generator=g).to(dev)
+    grads = []
+    for fused in (True, False):
+        L, R, H = ((torch.randn(2, n, generator=torch.Generator().manual_seed(n)) * 0.1).to(dev).requires_grad_(True) for n in (48, 48, 64))
+        if fused:
+            _, _, loss = model.CURLLayerWithLoss(msssim_layer=None)(img, None, L, R, H, tgt)
+        else:
+            out, _ = model.CURLLayer()(img, None, L, R, H)
+            loss = model.CURLLoss(msssim_layer=None)(out, tgt, None)
+        loss.backward()
+        grads.append((float(loss.detach()), L.grad, R.grad, H.grad))
+    assert grads[0][0] == grads[1][0]
+    for a, b in zip(grads[0][1:], grads[1][1:]):
+        assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
