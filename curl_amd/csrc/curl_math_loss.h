@@ -149,6 +149,24 @@ CURL_HD float sign0(float x) {
 #endif
 }
 
+// w * torch.sign(x) in three instructions where `w * sign0(x)` takes four: the second scaling carries the weight,
+// (x 2^100) (2^100 w) has the sign of x w and -- for any nonzero float32 x and |w| >= 1e-15 -- a magnitude far above |w|, so the
+// median with -|w| and +|w| is exactly w sign(x); x = 0 gives 0.  (The weights are d loss / d sum divided by the pixel count:
+// 1e-7 ... 1; an |x| above 2^27 would overflow the first product -- differences of values in [0, 1] do not.)
+struct SignW {
+  float bw, aw;  // 2^100 w, |w|
+};
+CURL_HD SignW signw_of(float w) { return SignW{0x1p100f * w, fabsf(w)}; }
+CURL_HD float signw(float x, float w, const SignW& k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)w;
+  return __builtin_amdgcn_fmed3f((x * 0x1p100f) * k.bw, -k.aw, k.aw);
+#else
+  (void)k;
+  return w * sign0(x);
+#endif
+}
+
 // d(sum_k w[k] * term_k + gLp * Lp) / d pred for one pixel; w = weights of (rgb_l1, cos_sim, lab_l1, hsv_l1).
 CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float gLp) {
   // The differences below feed torch.sign: contracted into fma(v s, cos, -cone_t) -- exact product minus rounded product -- a
@@ -158,7 +176,8 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
 #pragma clang fp contract(off)
   Px p{pred.c0 * m, pred.c1 * m, pred.c2 * m}, t{tgt.c0 * m, tgt.c1 * m, tgt.c2 * m};
   // rgb L1
-  Px g{w[0] * sign0(p.c0 - t.c0), w[0] * sign0(p.c1 - t.c1), w[0] * sign0(p.c2 - t.c2)};
+  const SignW k0 = signw_of(w[0]), k2 = signw_of(w[2]), k3 = signw_of(w[3]);  // (loop-invariant: once per wave)
+  Px g{signw(p.c0 - t.c0, w[0], k0), signw(p.c1 - t.c1, w[0], k0), signw(p.c2 - t.c2, w[0], k0)};
   // cosine similarity: c = d / (max(np,eps) max(nt,eps))
   float d = fmaf(p.c2, t.c2, fmaf(p.c1, t.c1, p.c0 * t.c0));
   float np = loss_sqrt(fmaf(p.c2, p.c2, fmaf(p.c1, p.c1, p.c0 * p.c0))), nt = loss_sqrt(fmaf(t.c2, t.c2, fmaf(t.c1, t.c1, t.c0 * t.c0)));
@@ -177,8 +196,8 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
   Rgb2LabT tape_lab, tape_unused;
   Px lp = rgb2lab_t(p, tape_lab), lt = rgb2lab_t(t, tape_unused);
   Px lpc{clamp01(lp.c0), clamp01(lp.c1), clamp01(lp.c2)}, ltc{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
-  Px gl{fmaf(w[2], sign0(lpc.c0 - ltc.c0), gLp) * pass01(lp.c0), w[2] * sign0(lpc.c1 - ltc.c1) * pass01(lp.c1),
-        w[2] * sign0(lpc.c2 - ltc.c2) * pass01(lp.c2)};
+  Px gl{(signw(lpc.c0 - ltc.c0, w[2], k2) + gLp) * pass01(lp.c0), signw(lpc.c1 - ltc.c1, w[2], k2) * pass01(lp.c1),
+        signw(lpc.c2 - ltc.c2, w[2], k2) * pass01(lp.c2)};
   Px g_lab = rgb2lab_pull(tape_lab, gl);
   // HSV cone L1
   // (the taped converter for both colours, as for Lab: one evaluation of the prediction's forward instead of rgb2hsv +
@@ -186,7 +205,7 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
   Rgb2HsvT tape_hsv, tape_hsv_unused;
   Px hp = rgb2hsv_t(p, tape_hsv);
   Px cp = hsv_cone(hp), ct = hsv_cone(rgb2hsv_t(t, tape_hsv_unused));
-  float ge0 = w[3] * sign0(cp.c0 - ct.c0), ge1 = w[3] * sign0(cp.c1 - ct.c1), ge2 = w[3] * sign0(cp.c2 - ct.c2);
+  float ge0 = signw(cp.c0 - ct.c0, w[3], k3), ge1 = signw(cp.c1 - ct.c1, w[3], k3), ge2 = signw(cp.c2 - ct.c2, w[3], k3);
   float h = hp.c0, s = hp.c1, v = hp.c2;  // in [1e-9, 1]: model.py:66's clamp is the identity and its gate passes (hsv_cone)
   float ca, sa;
   cos_sin_turns(h, ca, sa);
