@@ -105,7 +105,7 @@ WORKLOADS = {
                           "and target + the two L planes), bool mask all ones", bpp=33.0, frag="loss_terms_kernel",
                      mask="ones", bound="valu", flop_px=241.2),
     "loss_bwd": dict(desc="CURLLoss pointwise terms backward (gradient w.r.t. the prediction)", bpp=41.0,
-                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=347.8),
+                     frag="loss_terms_bwd_kernel", mask="ones", bound="valu", flop_px=344.8),
     "train_fwd": dict(desc="the train step's forward in ONE pass (curl_layer_loss_fwd_f32, main.py:283-285: CURLLayer.forward + "
                            "CURLLoss' pointwise terms on the prediction in registers; out, reg, 5 sums, both L planes), bool mask all "
                            "ones", bpp=45.0, frag="layer_loss_kernel", mask="ones", bound="valu", flop_px=439.2),

@@ -195,9 +195,13 @@ CURL_HD Px loss_terms_bwd(Px pred, Px tgt, float m, const float (&w)[4], float g
   // the reference, or sign(lp - lt) would be +-1 where torch.sign(0) is 0.
   Rgb2LabT tape_lab, tape_unused;
   Px lp = rgb2lab_t(p, tape_lab), lt = rgb2lab_t(t, tape_unused);
-  Px lpc{clamp01(lp.c0), clamp01(lp.c1), clamp01(lp.c2)}, ltc{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
-  Px gl{(signw(lpc.c0 - ltc.c0, w[2], k2) + gLp) * pass01(lp.c0), signw(lpc.c1 - ltc.c1, w[2], k2) * pass01(lp.c1),
-        signw(lpc.c2 - ltc.c2, w[2], k2) * pass01(lp.c2)};
+  // model.py:55's clamp and its gradient gate [0 <= x <= 1] from ONE compare each (clamp_gate), applied as a select: as
+  // `value * pass01(x)` a gate was clamp + compare + select(1.0) + multiply
+  lmask gate0, gate1, gate2;
+  Px lpc{clamp_gate(lp.c0, 0.0f, 1.0f, gate0), clamp_gate(lp.c1, 0.0f, 1.0f, gate1), clamp_gate(lp.c2, 0.0f, 1.0f, gate2)};
+  Px ltc{clamp01(lt.c0), clamp01(lt.c1), clamp01(lt.c2)};
+  Px gl{lm_keep(gate0, signw(lpc.c0 - ltc.c0, w[2], k2) + gLp), lm_keep(gate1, signw(lpc.c1 - ltc.c1, w[2], k2)),
+        lm_keep(gate2, signw(lpc.c2 - ltc.c2, w[2], k2))};
   Px g_lab = rgb2lab_pull(tape_lab, gl);
   // HSV cone L1
   // (the taped converter for both colours, as for Lab: one evaluation of the prediction's forward instead of rgb2hsv +
